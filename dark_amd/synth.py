@@ -1,0 +1,100 @@
+"""Deterministic synthetic weights and query batches (no dataset, no tokenizer, no checkpoint).
+
+Weights follow the reference's ``_init_weights`` distribution
+(modeling_dream_length.py:538-547: normal(0, 0.02), zero biases, zero pad row,
+unit norm weights); ``rich=True`` additionally randomises biases and norm
+weights so parity tests exercise them.
+
+Inputs follow the fixed layouts the reference builds on the host
+(akgr/tokenizer.py:287-338): ``[BOS, query x10, SEP, obs x32, EOS]``
+with the query (abduction) or the observation (deduction) side masked.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+
+# special ids, akgr/configs/config-dataloader.yml:1-15
+BOS, END, UNK, SEP, EXPAND, MASK = 0, 2, 3, 4, 5, 6
+OPS = (15, 16, 17)
+OFFSET = 100
+QRY_LEN, ANS_LEN = 10, 32
+FB15K237 = dict(nentity=14505, nrelation=474)   # V = 100 + 14505 + 474 + 1 = 15080
+DBPEDIA50 = dict(nentity=24624, nrelation=702)  # V = 25427
+
+
+def vocab_size(nentity: int, nrelation: int) -> int:
+    """ntoken + 1 (akgr/tokenizer.py:19-27, akgr/abduction_model/main.py:528)."""
+    return OFFSET + nentity + nrelation + 1
+
+
+def state_dict_layout(vocab: int, d: int, ff: int, layers: int) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Names/shapes of ``DreamModel_length.state_dict()`` in order."""
+    names: List[Tuple[str, Tuple[int, ...]]] = [("model.embed_tokens.weight", (vocab, d))]
+    for i in range(layers):
+        p = f"model.layers.{i}."
+        names += [
+            (p + "self_attn.q_proj.weight", (d, d)), (p + "self_attn.q_proj.bias", (d,)),
+            (p + "self_attn.k_proj.weight", (d, d)), (p + "self_attn.k_proj.bias", (d,)),
+            (p + "self_attn.v_proj.weight", (d, d)), (p + "self_attn.v_proj.bias", (d,)),
+            (p + "self_attn.o_proj.weight", (d, d)),
+            (p + "mlp.gate_proj.weight", (ff, d)), (p + "mlp.up_proj.weight", (ff, d)),
+            (p + "mlp.down_proj.weight", (d, ff)),
+            (p + "input_layernorm.weight", (d,)), (p + "post_attention_layernorm.weight", (d,)),
+        ]
+    names += [("model.norm.weight", (d,)), ("lm_head.weight", (vocab, d))]
+    return names
+
+
+def make_weights(config, seed: int = 0, rich: bool = False, std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """fp32 CPU state_dict for ``config`` (anything with the DreamConfig shape attributes)."""
+    g = torch.Generator().manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in state_dict_layout(config.vocab_size, config.hidden_size, config.intermediate_size,
+                                         config.num_hidden_layers):
+        if name.endswith("norm.weight") or name.endswith("layernorm.weight"):
+            t = torch.ones(shape)
+            if rich:
+                t = t + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith(".bias"):
+            t = torch.randn(shape, generator=g) * std if rich else torch.zeros(shape)
+        else:
+            t = torch.randn(shape, generator=g) * std
+        out[name] = t
+    pad = getattr(config, "pad_token_id", None)
+    if pad is not None and 0 <= pad < config.vocab_size:
+        out["model.embed_tokens.weight"][pad].zero_()
+    return out
+
+
+def make_inputs(batch: int, kind: str = "abd", nentity: int = FB15K237["nentity"],
+                nrelation: int = FB15K237["nrelation"], seed: int = 1) -> torch.Tensor:
+    """int64 ``[batch, 45]`` ids in the reference's fixed layout; ``kind`` in {"abd", "ded"}."""
+    g = torch.Generator().manual_seed(seed)
+    n_in = 1 + QRY_LEN + 1 + ANS_LEN + 1
+    x = torch.full((batch, n_in), END, dtype=torch.long)
+    x[:, 0] = BOS
+    x[:, 1 + QRY_LEN] = SEP
+    ent_lo, rel_lo = OFFSET, OFFSET + nentity
+    if kind == "abd":
+        x[:, 1:1 + QRY_LEN] = MASK
+        n_ans = torch.randint(1, ANS_LEN + 1, (batch,), generator=g)
+        # sorted, distinct entity ids: sorted uniforms over a range shrunk by ANS_LEN, plus arange
+        r = torch.rand(batch, ANS_LEN, generator=g).sort(dim=1).values
+        ents = (r * (nentity - ANS_LEN)).long() + torch.arange(ANS_LEN) + ent_lo
+        keep = torch.arange(ANS_LEN)[None, :] < n_ans[:, None]
+        x[:, 2 + QRY_LEN:2 + QRY_LEN + ANS_LEN] = torch.where(keep, ents, torch.full_like(ents, END))
+    elif kind == "ded":
+        x[:, 2 + QRY_LEN:2 + QRY_LEN + ANS_LEN] = MASK
+        n_act = torch.randint(2, QRY_LEN + 1, (batch,), generator=g)
+        kinds = torch.randint(0, 3, (batch, QRY_LEN), generator=g)
+        ops = torch.tensor(OPS)[torch.randint(0, 3, (batch, QRY_LEN), generator=g)]
+        rels = torch.randint(rel_lo, rel_lo + nrelation, (batch, QRY_LEN), generator=g)
+        ents = torch.randint(ent_lo, ent_lo + nentity, (batch, QRY_LEN), generator=g)
+        acts = torch.where(kinds == 0, ops, torch.where(kinds == 1, rels, ents))
+        keep = torch.arange(QRY_LEN)[None, :] < n_act[:, None]
+        x[:, 1:1 + QRY_LEN] = torch.where(keep, acts, torch.full_like(acts, END))
+    else:
+        raise ValueError(f"unknown layout kind: {kind}")
+    return x

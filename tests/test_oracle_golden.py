@@ -1,0 +1,104 @@
+"""Pins the CPU oracle against fixtures generated from the reference's own code
+(tests/golden/make_goldens.py).  Token ids / unmask order must be identical; floats within 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from dark_amd import synth
+from oracle import dream_oracle as O
+
+
+def _cfg(kw):
+    return O.OracleConfig(**{k: v for k, v in kw.items() if k in O.OracleConfig.__dataclass_fields__})
+
+
+@pytest.fixture(scope="module")
+def mini(golden_meta, goldens):
+    cfg = _cfg(golden_meta["mini"])
+    w = synth.make_weights(cfg, seed=0, rich=True)
+    chk = np.array([float(w[k].double().sum()) for k in sorted(w)])
+    np.testing.assert_allclose(chk, goldens["mini_w_checksum"], rtol=0, atol=0)
+    return cfg, w
+
+
+def test_forward_hidden_and_logits(mini, goldens):
+    cfg, w = mini
+    ids = torch.from_numpy(goldens["fwd_ids"])
+    B, N = ids.shape
+    full = torch.ones(B, 1, N, N, dtype=torch.bool)
+    pos = torch.arange(N).unsqueeze(0).expand(B, -1)
+    col = []
+    h = O.forward_hidden(w, cfg, ids, full, pos, collect=col)
+    ref_h = goldens["fwd_hidden"]  # embed, after layer 0, final-normed last
+    np.testing.assert_allclose(col[0].numpy(), ref_h[0], atol=1e-6)
+    np.testing.assert_allclose(col[1].numpy(), ref_h[1], atol=1e-5)
+    np.testing.assert_allclose(h.numpy(), ref_h[-1], atol=1e-5)
+    logits = torch.nn.functional.linear(h, w["lm_head.weight"])
+    np.testing.assert_allclose(logits.numpy(), goldens["fwd_logits"], atol=1e-5)
+
+
+def test_forward_padded_mask(mini, goldens):
+    cfg, w = mini
+    ids = torch.from_numpy(goldens["fwd_ids"])
+    am = torch.from_numpy(goldens["fwdpad_mask"])
+    tok = am.cumsum(-1) - 1
+    tok.masked_fill_(am == 0, 1)
+    m4 = torch.logical_and(am.unsqueeze(1).unsqueeze(-2), am.unsqueeze(1).unsqueeze(-1))
+    logits = O.forward_logits(w, cfg, ids, m4, tok)
+    np.testing.assert_allclose(logits.numpy(), goldens["fwdpad_logits"], atol=1e-5)
+
+
+def test_sample_tokens(goldens, golden_meta):
+    logits = torch.from_numpy(goldens["st_logits"])
+    for ci, c in enumerate(golden_meta["cases"]["sample_tokens"]):
+        torch.manual_seed(c["seed"])
+        conf, x0 = O.sample_tokens(logits, temperature=c["T"], top_p=c["top_p"], top_k=c["top_k"],
+                                   margin_confidence=c["margin"], neg_entropy=c["neg_entropy"])
+        assert np.array_equal(x0.numpy(), goldens[f"st{ci}_x0"]), f"case {ci}"
+        np.testing.assert_allclose(conf.numpy(), goldens[f"st{ci}_conf"], rtol=1e-6, atol=1e-7)
+
+
+def _run_loop(cfg, w, ids, case, attention_mask=None):
+    kw = dict(case["kw"])
+    torch.manual_seed(case["seed"])
+    seq, hist = O.sample_loop(w, cfg, ids, max_length=ids.shape[1] + 1, mask_token_id=synth.MASK,
+                              attention_mask=attention_mask, steps=kw["steps"], alg=kw["alg"],
+                              alg_temp=kw.get("alg_temp"), temperature=kw["temperature"],
+                              top_p=kw.get("top_p"), top_k=kw.get("top_k"))
+    return torch.stack(hist).numpy()
+
+
+def test_loops_mini(mini, goldens, golden_meta):
+    cfg, w = mini
+    for case in golden_meta["cases"]["loops"]:
+        name = case["name"]
+        if "ids" in case:
+            ids = torch.from_numpy(goldens[case["ids"]])
+        else:
+            ids = torch.from_numpy(goldens["loop_abd_ids" if name.startswith("abd") else "loop_ded_ids"])
+        am = torch.from_numpy(goldens[case["attention_mask"]]) if "attention_mask" in case else None
+        hist = _run_loop(cfg, w, ids, case, am)
+        assert np.array_equal(hist, goldens[name + "_hist"]), name
+
+
+def test_transfer_schedule():
+    # k per step emulated with torch fp32
+    assert O.transfer_schedule(11, 16) == [0] * 6 + [1] * 9 + [2]
+    assert O.transfer_schedule(11, 32) == [0] * 22 + [1] * 9 + [2]
+    assert O.transfer_schedule(11, 64) == [0] * 54 + [1] * 9 + [2]
+    assert O.transfer_schedule(33, 32) == [1] * 31 + [2]
+    assert O.transfer_schedule(65, 32) == [2] * 31 + [3]
+
+
+def test_real_shape(goldens, golden_meta):
+    cfg = _cfg(golden_meta["real"])
+    w = synth.make_weights(cfg, seed=0, rich=False)
+    chk = np.array([float(w["lm_head.weight"].double().sum()),
+                    float(w["model.layers.9.mlp.down_proj.weight"].double().sum())])
+    np.testing.assert_allclose(chk, goldens["real_w_checksum"], rtol=0, atol=0)
+    ids = torch.from_numpy(goldens["real_abd_ids"])
+    x = torch.nn.functional.pad(ids, (0, 1), value=synth.MASK)
+    lg = O.forward_logits(w, cfg, x[:1], torch.ones(1, 1, 46, 46, dtype=torch.bool), torch.arange(46).unsqueeze(0))
+    np.testing.assert_allclose(lg[0, :3].numpy(), goldens["real_logits_row0_pos0_3"], atol=2e-5)
+    case = dict(seed=2, kw=dict(steps=16, temperature=0.1, alg="entropy", alg_temp=0, top_p=0.9))
+    assert np.array_equal(_run_loop(cfg, w, ids, case), goldens["real_abd_t01_hist"])
