@@ -1,0 +1,33 @@
+"""dark_amd: MI355X-native denoise / unmask hot path of DARK behind the reference's Python surface.
+
+    from dark_amd import DreamConfig, DreamGenerationConfig, DreamModel_length
+
+`dark_amd.install_akgr_alias()` additionally registers the package under the reference's module path
+(`akgr.abduction_model.model.custom_mydream.*`) so callers written against the reference import it unchanged.
+"""
+import sys
+import types
+
+from .configuration_dream import DreamConfig
+from .generation_utils import DreamGenerationConfig, DreamGenerationMixin, DreamModelOutput
+from .modeling_dream_length import DreamModel_length
+
+__all__ = ["DreamConfig", "DreamGenerationConfig", "DreamGenerationMixin", "DreamModelOutput",
+           "DreamModel_length", "install_akgr_alias"]
+
+
+def install_akgr_alias() -> None:
+    """Expose this package as akgr.abduction_model.model.custom_mydream."""
+    from . import configuration_dream, generation_utils, modeling_dream_length
+    chain = ["akgr", "akgr.abduction_model", "akgr.abduction_model.model",
+             "akgr.abduction_model.model.custom_mydream"]
+    for name in chain:
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    base = chain[-1]
+    for sub, mod in (("configuration_dream", configuration_dream), ("generation_utils", generation_utils),
+                     ("modeling_dream_length", modeling_dream_length)):
+        sys.modules[f"{base}.{sub}"] = mod
+        setattr(sys.modules[base], sub, mod)

@@ -1,0 +1,116 @@
+"""ctypes binding of ``libdark_hip.so`` (C ABI in ``include/dark_hip.h``).
+
+The library is the product: if it is missing or cannot be loaded this module raises, it never
+falls back to a CPU or PyTorch implementation.  Build it with ``python -c "import __graft_entry__ as g;
+g.build()"`` or ``make -C dark_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdark_hip.so")
+
+DARK_OK = 0
+DARK_F32, DARK_BF16 = 0, 1
+CONF_PROB, CONF_MARGIN, CONF_NEG_ENTROPY = 0, 1, 2
+ABI_VERSION = 1
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [("w_qkv", C.c_void_p), ("b_qkv", C.c_void_p), ("w_o", C.c_void_p), ("w_gu", C.c_void_p),
+                ("w_down", C.c_void_p), ("ln1", C.c_void_p), ("ln2", C.c_void_p)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("vocab", C.c_int32), ("vocab_pad", C.c_int32), ("d", C.c_int32),
+                ("ff", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("head_dim", C.c_int32),
+                ("max_pos", C.c_int32), ("rms_eps", C.c_float), ("embed", C.c_void_p),
+                ("final_norm", C.c_void_p), ("lm_head", C.c_void_p), ("rope_cos", C.c_void_p),
+                ("rope_sin", C.c_void_p), ("layers", C.POINTER(LayerWeights))]
+
+
+# name -> (restype, argtypes); every symbol include/dark_hip.h declares
+SIGNATURES = {
+    "dark_hip_abi_version": (C.c_int, []),
+    "dark_hip_last_error": (C.c_char_p, []),
+    "dark_forward_workspace_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.c_int, C.c_int]),
+    "dark_head_workspace_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.c_int]),
+    "dark_step_workspace_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int]),
+    "dark_step_workspace_offsets": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(C.c_size_t)]),
+    "dark_forward_hidden": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "dark_lm_head_rows": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_int64, C.c_void_p]),
+    "dark_mask_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
+    "dark_sample_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dark_commit_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.c_void_p]),
+    "dark_denoise_step": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dark_dbg_gemm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                C.c_int, C.c_int64, C.c_void_p]),
+    "dark_dbg_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dark_dbg_rmsnorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_float, C.c_void_p]),
+    "dark_dbg_embed": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class DarkHipError(RuntimeError):
+    """A C-ABI call returned a DARK_ERR_* code (message from dark_hip_last_error)."""
+
+
+def load() -> C.CDLL:
+    """dlopen the library and bind every symbol; raises if anything is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP library is the only implementation of this path. "
+            "Build it with `make -C dark_amd/csrc` (hipcc, --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.dark_hip_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libdark_hip.so ABI version {got}, binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != DARK_OK:
+        msg = load().dark_hip_last_error()
+        raise DarkHipError(f"dark_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous CUDA/HIP tensor (None passes NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("dark_hip entry points take device memory; got a CPU tensor")
+    if not t.is_contiguous():
+        raise ValueError("dark_hip entry points take contiguous tensors")
+    return t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> int:
+    """hipStream_t of torch's current stream on `device`, as an integer handle."""
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,229 @@
+// extern "C" entry points of libdark_hip.so (declared in include/dark_hip.h) and the per-step
+// launch sequence.  Nothing here allocates or synchronises; every call only enqueues on `stream`.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace dark {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static size_t esize(int dtype) { return dtype == DARK_BF16 ? 2 : 4; }
+
+static int check_model(const dark_model_desc* m) {
+  DARK_CHECK_ARG(m != nullptr, "null model descriptor");
+  DARK_CHECK_ARG(m->dtype == DARK_F32 || m->dtype == DARK_BF16, "bad dtype %d", m->dtype);
+  DARK_CHECK_ARG(m->d > 0 && m->d % 64 == 0, "hidden_size=%d must be a positive multiple of 64", m->d);
+  DARK_CHECK_ARG(m->ff > 0 && m->ff % 64 == 0, "intermediate_size=%d must be a positive multiple of 64", m->ff);
+  DARK_CHECK_ARG(m->n_heads > 0 && m->n_heads * m->head_dim == m->d, "heads %d x head_dim %d != hidden %d",
+                 m->n_heads, m->head_dim, m->d);
+  DARK_CHECK_ARG(m->head_dim == 64 || m->head_dim == 96, "head_dim=%d must be 64 or 96", m->head_dim);
+  DARK_CHECK_ARG(m->vocab >= 2 && m->vocab_pad >= m->vocab && m->vocab_pad % 128 == 0,
+                 "vocab=%d vocab_pad=%d (pad must be a multiple of 128)", m->vocab, m->vocab_pad);
+  DARK_CHECK_ARG(m->n_layers >= 0 && (m->n_layers == 0 || m->layers), "layers missing");
+  DARK_CHECK_ARG(m->embed && m->final_norm && m->lm_head && m->rope_cos && m->rope_sin, "null weight pointer");
+  DARK_CHECK_ARG(m->max_pos >= 1, "max_pos=%d", m->max_pos);
+  return DARK_OK;
+}
+
+struct FwdWs {
+  char *xn, *qkv, *att, *act;
+  size_t total;
+};
+static FwdWs carve_fwd(const dark_model_desc* m, size_t rows, char* base) {
+  const size_t es = esize(m->dtype);
+  FwdWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
+  w.xn = take(rows * m->d * es);
+  w.qkv = take(rows * 3 * m->d * es);
+  w.att = take(rows * m->d * es);
+  w.act = take(rows * m->ff * es);
+  w.total = off;
+  return w;
+}
+
+static int forward_hidden(const dark_model_desc* m, const int64_t* ids, const int32_t* pos,
+                          const uint8_t* key_mask, int B, int N, void* workspace, size_t ws_bytes,
+                          float* hidden, hipStream_t st) {
+  DARK_TRY(check_model(m));
+  DARK_CHECK_ARG(B > 0 && N > 0 && N <= 128, "forward: B=%d N=%d (N must be in [1,128])", B, N);
+  DARK_CHECK_ARG((int64_t)B * N < (1ll << 30), "forward: B*N too large");
+  DARK_CHECK_ARG(ids && hidden && workspace, "forward: null pointer");
+  DARK_CHECK_ARG(pos != nullptr || N <= m->max_pos, "forward: N=%d exceeds the RoPE table (%d rows)", N, m->max_pos);
+  const int M = B * N, d = m->d;
+  FwdWs w = carve_fwd(m, (size_t)M, (char*)workspace);
+  DARK_CHECK_ARG(ws_bytes >= w.total, "forward: workspace %zu < required %zu bytes", ws_bytes, w.total);
+
+  DARK_TRY(launch_embed(m->dtype, ids, m->embed, hidden, M, d, m->vocab, st));
+  for (int l = 0; l < m->n_layers; ++l) {
+    const dark_layer_weights& L = m->layers[l];
+    DARK_CHECK_ARG(L.w_qkv && L.b_qkv && L.w_o && L.w_gu && L.w_down && L.ln1 && L.ln2, "layer %d: null weight", l);
+    DARK_TRY(launch_rmsnorm(m->dtype, hidden, L.ln1, w.xn, nullptr, M, M, d, m->rms_eps, st));
+    DARK_TRY(launch_gemm(m->dtype, EPI_BIAS, w.xn, L.w_qkv, L.b_qkv, w.qkv, M, 3 * d, d, 3 * d, st));
+    DARK_TRY(launch_attention(m->dtype, w.qkv, m->rope_cos, m->rope_sin, pos, key_mask, w.att, B, N, m->n_heads,
+                              m->head_dim, m->max_pos, st));
+    DARK_TRY(launch_gemm(m->dtype, EPI_RESID, w.att, L.w_o, nullptr, hidden, M, d, d, d, st));
+    DARK_TRY(launch_rmsnorm(m->dtype, hidden, L.ln2, w.xn, nullptr, M, M, d, m->rms_eps, st));
+    DARK_TRY(launch_gemm(m->dtype, EPI_SWIGLU, w.xn, L.w_gu, nullptr, w.act, M, 2 * m->ff, d, m->ff, st));
+    DARK_TRY(launch_gemm(m->dtype, EPI_RESID, w.act, L.w_down, nullptr, hidden, M, d, m->ff, d, st));
+  }
+  return DARK_OK;
+}
+
+static int lm_head_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int n_src, int M,
+                        void* workspace, size_t ws_bytes, float* logits, int64_t ldl, hipStream_t st) {
+  DARK_TRY(check_model(m));
+  if (M <= 0) return DARK_OK;
+  DARK_CHECK_ARG(hidden && workspace && logits, "lm_head_rows: null pointer");
+  DARK_CHECK_ARG(ldl >= m->vocab, "lm_head_rows: ldl=%lld < vocab=%d", (long long)ldl, m->vocab);
+  const size_t need = align_up((size_t)M * m->d * esize(m->dtype), 256);
+  DARK_CHECK_ARG(ws_bytes >= need, "lm_head_rows: workspace %zu < required %zu bytes", ws_bytes, need);
+  DARK_TRY(launch_rmsnorm(m->dtype, hidden, m->final_norm, workspace, src_rows, n_src, M, m->d, m->rms_eps, st));
+  DARK_TRY(launch_gemm(m->dtype, EPI_F32, workspace, m->lm_head, nullptr, logits, M, m->vocab, m->d, ldl, st));
+  return DARK_OK;
+}
+
+struct StepWs {
+  char* fwd;
+  float* hidden;
+  int32_t *row_index, *src_rows, *count;
+  char* head;
+  float* logits;
+  float* conf;
+  int64_t* x0;
+  size_t fwd_bytes, head_bytes, total;
+};
+static StepWs carve_step(const dark_model_desc* m, int B, int N, int M, char* base) {
+  StepWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
+  const size_t rows = (size_t)B * N;
+  w.fwd_bytes = carve_fwd(m, rows, nullptr).total;
+  w.fwd = take(w.fwd_bytes);
+  w.hidden = (float*)take(rows * m->d * 4);
+  w.row_index = (int32_t*)take(rows * 4);
+  w.src_rows = (int32_t*)take(rows * 4);
+  w.count = (int32_t*)take(16);
+  w.head_bytes = align_up((size_t)M * m->d * esize(m->dtype), 256);
+  w.head = take(w.head_bytes);
+  w.logits = (float*)take((size_t)M * m->vocab * 4);
+  w.conf = (float*)take((size_t)M * 4);
+  w.x0 = (int64_t*)take((size_t)M * 8);
+  w.total = off;
+  return w;
+}
+
+}  // namespace dark
+
+using namespace dark;
+
+extern "C" {
+
+int dark_hip_abi_version(void) { return DARK_HIP_ABI_VERSION; }
+const char* dark_hip_last_error(void) { return g_err; }
+
+size_t dark_forward_workspace_bytes(const dark_model_desc* m, int B, int N) {
+  if (!m || B <= 0 || N <= 0) return 0;
+  return carve_fwd(m, (size_t)B * N, nullptr).total;
+}
+size_t dark_head_workspace_bytes(const dark_model_desc* m, int M) {
+  if (!m || M <= 0) return 0;
+  return align_up((size_t)M * m->d * esize(m->dtype), 256);
+}
+size_t dark_step_workspace_bytes(const dark_model_desc* m, int B, int N, int M) {
+  if (!m || B <= 0 || N <= 0 || M < 0) return 0;
+  return carve_step(m, B, N, M, nullptr).total;
+}
+
+int dark_step_workspace_offsets(const dark_model_desc* m, int B, int N, int M, size_t* out7) {
+  DARK_CHECK_ARG(m && out7 && B > 0 && N > 0 && M >= 0, "step_workspace_offsets: bad argument");
+  StepWs w = carve_step(m, B, N, M, nullptr);
+  out7[0] = (size_t)((char*)w.hidden - (char*)nullptr);
+  out7[1] = (size_t)((char*)w.row_index - (char*)nullptr);
+  out7[2] = (size_t)((char*)w.src_rows - (char*)nullptr);
+  out7[3] = (size_t)((char*)w.count - (char*)nullptr);
+  out7[4] = (size_t)((char*)w.logits - (char*)nullptr);
+  out7[5] = (size_t)((char*)w.conf - (char*)nullptr);
+  out7[6] = (size_t)((char*)w.x0 - (char*)nullptr);
+  return DARK_OK;
+}
+
+int dark_forward_hidden(const dark_model_desc* m, const int64_t* ids, const int32_t* pos, const uint8_t* key_mask,
+                        int B, int N, void* workspace, size_t workspace_bytes, float* hidden, void* stream) {
+  return forward_hidden(m, ids, pos, key_mask, B, N, workspace, workspace_bytes, hidden, (hipStream_t)stream);
+}
+
+int dark_lm_head_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M, void* workspace,
+                      size_t workspace_bytes, float* logits, int64_t ldl, void* stream) {
+  // src_rows entries are clamped to < 2^30 rows; callers pass indices produced by dark_mask_rows
+  return lm_head_rows(m, hidden, src_rows, 1 << 30, M, workspace, workspace_bytes, logits, ldl, (hipStream_t)stream);
+}
+
+int dark_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* row_index, int32_t* src_rows,
+                   int32_t* count, void* stream) {
+  DARK_CHECK_ARG(x && row_index && src_rows && count, "mask_rows: null pointer");
+  return launch_mask_rows(x, B, N, mask_id, row_index, src_rows, count, (hipStream_t)stream);
+}
+
+int dark_sample_rows(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
+                     int conf_mode, const float* noise, int64_t ldn, float* conf, int64_t* x0, void* stream) {
+  return launch_sample(logits, ldl, M, V, temperature, top_p, top_k, conf_mode, noise, ldn, conf, x0,
+                       (hipStream_t)stream);
+}
+
+int dark_commit_topk(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M, const float* conf,
+                     const int64_t* x0, int k, void* stream) {
+  DARK_CHECK_ARG(x && (M == 0 || (row_index && conf && x0)), "commit_topk: null pointer");
+  return launch_commit(x, B, N, mask_id, row_index, M, conf, x0, k, (hipStream_t)stream);
+}
+
+int dark_denoise_step(const dark_model_desc* m, int64_t* x, const int32_t* pos, const uint8_t* key_mask, int B, int N,
+                      int M, int64_t mask_id, float temperature, float top_p, int top_k, int conf_mode,
+                      const float* noise, int k, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DARK_TRY(check_model(m));
+  DARK_CHECK_ARG(x && workspace, "denoise_step: null pointer");
+  DARK_CHECK_ARG(B > 0 && N > 0 && M >= 0 && M <= B * N, "denoise_step: bad B=%d N=%d M=%d", B, N, M);
+  StepWs w = carve_step(m, B, N, M, (char*)workspace);
+  DARK_CHECK_ARG(workspace_bytes >= w.total, "denoise_step: workspace %zu < required %zu bytes", workspace_bytes,
+                 w.total);
+  DARK_TRY(forward_hidden(m, x, pos, key_mask, B, N, w.fwd, w.fwd_bytes, w.hidden, st));
+  if (M == 0) return DARK_OK;
+  DARK_TRY(launch_mask_rows(x, B, N, mask_id, w.row_index, w.src_rows, w.count, st));
+  DARK_TRY(lm_head_rows(m, w.hidden, w.src_rows, B * N, M, w.head, w.head_bytes, w.logits, m->vocab, st));
+  DARK_TRY(launch_sample(w.logits, m->vocab, M, m->vocab, temperature, top_p, top_k, conf_mode, noise, m->vocab,
+                         w.conf, w.x0, st));
+  DARK_TRY(launch_commit(x, B, N, mask_id, w.row_index, M, w.conf, w.x0, k, st));
+  return DARK_OK;
+}
+
+// ---- unit-test hooks: single-kernel launches (tests/test_hip_kernels.py) ----
+int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                  int64_t ldo, void* stream) {
+  return launch_gemm(dtype, epi, A, W, bias, out, M, N, K, ldo, (hipStream_t)stream);
+}
+int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
+                       const uint8_t* key_mask, void* out, int B, int N, int H, int HD, int max_pos, void* stream) {
+  DARK_CHECK_ARG(qkv && cosT && sinT && out && B > 0 && H > 0, "dbg_attention: bad argument");
+  return launch_attention(dtype, qkv, cosT, sinT, pos, key_mask, out, B, N, H, HD, max_pos, (hipStream_t)stream);
+}
+int dark_dbg_rmsnorm(int dtype, const float* x, const float* w, void* out, const int32_t* src_rows, int n_src, int M,
+                     int d, float eps, void* stream) {
+  DARK_CHECK_ARG(x && w && out, "dbg_rmsnorm: null pointer");
+  return launch_rmsnorm(dtype, x, w, out, src_rows, n_src, M, d, eps, (hipStream_t)stream);
+}
+int dark_dbg_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+                   void* stream) {
+  DARK_CHECK_ARG(ids && table && out && M > 0, "dbg_embed: bad argument");
+  return launch_embed(dtype, ids, table, out, M, d, vocab, (hipStream_t)stream);
+}
+
+}  // extern "C"

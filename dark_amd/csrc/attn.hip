@@ -1,0 +1,258 @@
+// Fused bidirectional attention for short sequences (N <= 128): RoPE + QK^T + pad/mask + softmax + PV.
+//
+// Replaces apply_rotary_pos_emb (modeling_dream_length.py:183-207, :399) and
+// F.scaled_dot_product_attention(..., attn_mask=bool[B,1,N,N], is_causal=False) (:424-431).
+//
+// One workgroup per (sequence, head).  Q, K (rotated) and V of the head are staged once in LDS;
+// each wave then owns 16-query tiles.  Scores are computed TRANSPOSED (S^T = K Q^T) with 16x16 MFMA
+// so that a lane ends up holding, for ITS query (lane & 15), the keys 4*(lane>>4)+r of every key
+// tile: exactly the A-operand layout of the following P V MFMA.  P never touches LDS; the softmax
+// row reductions are two xor-shuffles (lanes l, l^16, l^32, l^48 share a query).  The pad/mask
+// vector is applied in-register as a per-key additive bias (0 / -inf).
+//   bf16: v_mfma_f32_16x16x32_bf16 (P rounded to bf16 for P V, fp32 accumulate)
+//   fp32: v_mfma_f32_16x16x4_f32   (exact fp32 fma chains)
+#include "common.h"
+
+namespace dark {
+
+template <typename T> struct AttnVec;
+template <> struct AttnVec<float> {
+  static constexpr int VEC = 4;
+  typedef float4 raw_t;
+  __device__ static __forceinline__ void unpack(const raw_t& r, float (&f)[4]) {
+    f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w;
+  }
+  __device__ static __forceinline__ raw_t pack(const float (&f)[4]) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <> struct AttnVec<bf16_t> {
+  static constexpr int VEC = 8;
+  typedef bf16x8 raw_t;
+  __device__ static __forceinline__ void unpack(const raw_t& r, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)r[i];
+  }
+  __device__ static __forceinline__ raw_t pack(const float (&f)[8]) {
+    raw_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16_t)f[i];
+    return r;
+  }
+};
+
+template <typename T, int HD, int NT>
+__global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qkv, const float* __restrict__ cosT,
+                                                   const float* __restrict__ sinT,
+                                                   const int32_t* __restrict__ pos,
+                                                   const uint8_t* __restrict__ kmask, T* __restrict__ out,
+                                                   int N, int H, int max_pos, float scale) {
+  constexpr int VEC = AttnVec<T>::VEC;
+  typedef typename AttnVec<T>::raw_t raw_t;
+  constexpr int NP = NT * 16;     // padded token count
+  constexpr int LD = HD + VEC;    // padded LDS row (elements): keeps 16-B alignment, breaks bank strides
+  constexpr int HALF = HD / 2;
+  constexpr int PC = HALF / VEC;  // 16-B chunk pairs per row for RoPE
+  constexpr int VC = HD / VEC;    // 16-B chunks per V row
+  constexpr bool kF32 = sizeof(T) == 4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* Qs = (T*)smem;
+  T* Ks = Qs + NP * LD;
+  T* Vs = Ks + NP * LD;
+  float* kbias = (float*)(Vs + NP * LD);  // [NP]: 0 = attend, -inf = masked / padding key
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int dm = H * HD;
+  const int64_t ld = 3 * (int64_t)dm;
+  const T* base = qkv + (int64_t)b * N * ld + h * HD;
+
+  // ---- stage Q, K with RoPE
+  for (int it = tid; it < 2 * NP * PC; it += 256) {
+    const int which = it / (NP * PC);
+    const int rem = it - which * (NP * PC);
+    const int t = rem / PC, c = rem - t * PC;
+    float o1[VEC], o2[VEC];
+    if (t < N) {
+      int p = pos ? pos[b * N + t] : t;
+      p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+      const T* src = base + (int64_t)t * ld + which * dm + c * VEC;
+      float x1[VEC], x2[VEC];
+      AttnVec<T>::unpack(*(const raw_t*)src, x1);
+      AttnVec<T>::unpack(*(const raw_t*)(src + HALF), x2);
+      const float* cp = cosT + (int64_t)p * HALF + c * VEC;
+      const float* sp = sinT + (int64_t)p * HALF + c * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float cs = cp[e], sn = sp[e];
+        o1[e] = x1[e] * cs - x2[e] * sn;
+        o2[e] = x2[e] * cs + x1[e] * sn;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o1[e] = o2[e] = 0.f;
+    }
+    T* dst = (which ? Ks : Qs) + t * LD + c * VEC;
+    *(raw_t*)dst = AttnVec<T>::pack(o1);
+    *(raw_t*)(dst + HALF) = AttnVec<T>::pack(o2);
+  }
+  // ---- stage V
+  for (int it = tid; it < NP * VC; it += 256) {
+    const int t = it / VC, c = it - t * VC;
+    raw_t v;
+    if (t < N) {
+      v = *(const raw_t*)(base + (int64_t)t * ld + 2 * dm + c * VEC);
+    } else {
+      float z[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) z[e] = 0.f;
+      v = AttnVec<T>::pack(z);
+    }
+    *(raw_t*)(Vs + t * LD + c * VEC) = v;
+  }
+  for (int j = tid; j < NP; j += 256) {
+    const bool on = j < N && (!kmask || kmask[b * N + j] != 0);
+    kbias[j] = on ? 0.f : -INFINITY;
+  }
+  __syncthreads();
+
+  const int li = lane & 15, g = lane >> 4;
+  const int n_t = (N + 15) >> 4;  // live 16-token tiles (queries and keys)
+  for (int it = wave; it < n_t; it += 4) {
+    // ---- S^T tiles: rows = keys, cols = queries
+    f32x4 S[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      S[jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (jt < n_t) {
+        const T* kr = Ks + (jt * 16 + li) * LD;
+        const T* qr = Qs + (it * 16 + li) * LD;
+        if constexpr (kF32) {
+#pragma unroll
+          for (int ks = 0; ks < HD / 4; ++ks)
+            S[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[ks * 4 + g], qr[ks * 4 + g], S[jt], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < HD / 32; ++ks)
+            S[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(kr + ks * 32 + g * 8),
+                                                            *(const bf16x8*)(qr + ks * 32 + g * 8), S[jt], 0, 0, 0);
+        }
+      }
+    }
+    // ---- softmax over keys for query qi = it*16 + li (keys jt*16 + 4g + r live in this lane)
+    const int qi = it * 16 + li;
+    const bool q_on = qi < N && (!kmask || kmask[b * N + qi] != 0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s = S[jt][r] * scale + kbias[jt * 16 + 4 * g + r];
+        S[jt][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = (mx == -INFINITY) ? 0.f : expf(S[jt][r] - mx);
+        S[jt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const bool live = q_on && sum > 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[jt][r] = live ? S[jt][r] / sum : 0.f;
+
+    // ---- O = P V
+    T* orow = out + ((int64_t)b * N) * dm + h * HD;
+    if constexpr (kF32) {
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          if (jt < n_t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(S[jt][r], Vs[(jt * 16 + 4 * g + r) * LD + dt * 16 + li],
+                                                         acc, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = it * 16 + 4 * g + r;
+          if (i < N) orow[(int64_t)i * dm + dt * 16 + li] = acc[r];
+        }
+      }
+    } else {
+      bf16x8 pa[NT / 2];
+#pragma unroll
+      for (int k2 = 0; k2 < NT / 2; ++k2)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) pa[k2][jj] = (bf16_t)S[2 * k2 + (jj >> 2)][jj & 3];
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k2 = 0; k2 < NT / 2; ++k2) {
+          if (2 * k2 < n_t) {
+            bf16x8 vb;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+              vb[jj] = Vs[((2 * k2 + (jj >> 2)) * 16 + 4 * g + (jj & 3)) * LD + dt * 16 + li];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[k2], vb, acc, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = it * 16 + 4 * g + r;
+          if (i < N) orow[(int64_t)i * dm + dt * 16 + li] = (bf16_t)acc[r];
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int HD, int NT>
+static int launch_attn_t(const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
+                         const uint8_t* kmask, void* out, int B, int N, int H, int max_pos, hipStream_t st) {
+  constexpr int VEC = AttnVec<T>::VEC;
+  constexpr int smem = 3 * NT * 16 * (HD + VEC) * (int)sizeof(T) + NT * 16 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    DARK_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<T, HD, NT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  const float scale = 1.0f / sqrtf((float)HD);
+  hipLaunchKernelGGL((attn_kernel<T, HD, NT>), dim3(B * H), dim3(256), smem, st, (const T*)qkv, cosT, sinT, pos,
+                     kmask, (T*)out, N, H, max_pos, scale);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+int launch_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
+                     const uint8_t* kmask, void* out, int B, int N, int H, int HD, int max_pos,
+                     hipStream_t st) {
+  DARK_CHECK_ARG(N >= 1 && N <= 128, "attention: N=%d must be in [1,128]", N);
+  DARK_CHECK_ARG(HD == 64 || HD == 96, "attention: head_dim=%d must be 64 or 96", HD);
+  DARK_CHECK_ARG(max_pos >= 1, "attention: empty RoPE table");
+  const bool small = N <= 64;
+#define DARK_ATTN(T, HDv)                                                                              \
+  return small ? launch_attn_t<T, HDv, 4>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st)       \
+               : launch_attn_t<T, HDv, 8>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st)
+  if (dtype == DARK_BF16) {
+    if (HD == 96) { DARK_ATTN(bf16_t, 96); } else { DARK_ATTN(bf16_t, 64); }
+  } else {
+    if (HD == 96) { DARK_ATTN(float, 96); } else { DARK_ATTN(float, 64); }
+  }
+#undef DARK_ATTN
+}
+
+}  // namespace dark

@@ -1,0 +1,126 @@
+// Shared device/host helpers for the DARK denoise hot path on gfx950 (MI355X, CDNA4).
+// Wave = 64 lanes everywhere in this directory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dark_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DARK_WAVE 64
+
+namespace dark {
+
+void set_error(const char* fmt, ...);
+
+#define DARK_CHECK_ARG(cond, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      ::dark::set_error(__VA_ARGS__);             \
+      return DARK_ERR_ARG;                        \
+    }                                             \
+  } while (0)
+
+#define DARK_CHECK_HIP(expr)                                                        \
+  do {                                                                              \
+    hipError_t e__ = (expr);                                                        \
+    if (e__ != hipSuccess) {                                                        \
+      ::dark::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),     \
+                        __FILE__, __LINE__);                                        \
+      return DARK_ERR_HIP;                                                          \
+    }                                                                               \
+  } while (0)
+
+#define DARK_CHECK_LAUNCH()                                                         \
+  do {                                                                              \
+    hipError_t e__ = hipGetLastError();                                             \
+    if (e__ != hipSuccess) {                                                        \
+      ::dark::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), \
+                        __FILE__, __LINE__);                                        \
+      return DARK_ERR_HIP;                                                          \
+    }                                                                               \
+  } while (0)
+
+#define DARK_TRY(expr)            \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != DARK_OK) return rc__; \
+  } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int kDtype = DARK_F32;
+  __device__ static __forceinline__ float to_f32(float v) { return v; }
+  __device__ static __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct ElemTraits<bf16_t> {
+  static constexpr int kDtype = DARK_BF16;
+  __device__ static __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+  __device__ static __forceinline__ bf16_t from_f32(float v) { return (bf16_t)v; }
+};
+
+// XCD-aware, bijective remap of a 1-D block id: blocks b and b+8 share an XCD (round-robin
+// dispatch), so give every XCD one contiguous chunk of the tile space for L2 reuse.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// ---- launchers implemented across the .hip files --------------------------
+// GEMM epilogues: C[M,N] = A[M,K] * W[N,K]^T (+...)
+enum Epi { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_F32 = 3 };
+
+// A: [M,K] dtype, W: [Npad,K] dtype (rows padded to a multiple of 128 with zeros).
+// EPI_BIAS  : out (dtype) [M,ldo] = acc + bias[n]
+// EPI_RESID : resid (fp32) [M,ldo] += acc
+// EPI_SWIGLU: W rows interleaved in groups of 32 (gate|up); out (dtype) [M,ldo], ldo cols = N/2
+// EPI_F32   : out (fp32) [M,ldo] = acc, columns n < N only
+int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out,
+                int M, int N, int K, int64_t ldo, hipStream_t st);
+
+int launch_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+                 hipStream_t st);
+// out[m] = w * (x[src(m)] * rsqrt(mean(x^2) + eps)); src_rows nullable (identity), else clamped to [0,n_src)
+int launch_rmsnorm(int dtype, const float* x, const float* w, void* out, const int32_t* src_rows, int n_src,
+                   int M, int d, float eps, hipStream_t st);
+int launch_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
+                     const uint8_t* kmask, void* out, int B, int N, int H, int HD, int max_pos,
+                     hipStream_t st);
+int launch_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* row_index,
+                     int32_t* src_rows, int32_t* count, hipStream_t st);
+int launch_sample(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p,
+                  int top_k, int conf_mode, const float* noise, int64_t ldn, float* conf, int64_t* x0,
+                  hipStream_t st);
+int launch_commit(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M,
+                  const float* conf, const int64_t* x0, int k, hipStream_t st);
+
+}  // namespace dark

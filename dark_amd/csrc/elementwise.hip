@@ -1,0 +1,214 @@
+// HBM-bound stages of the denoise step: embedding gather, RMSNorm (optionally over gathered
+// rows), mask-row compaction and the confidence-ranked commit.  One wave per row, 16-B accesses.
+#include "common.h"
+
+namespace dark {
+
+// ------------------------------------------------------------------ embedding (modeling_dream_length.py:665)
+template <typename TW>
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids,
+                                                    const TW* __restrict__ table,
+                                                    float* __restrict__ out, int M, int d, int vocab) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  int64_t id = ids[row];
+  // nn.Embedding raises on out-of-range ids; the host binding validates ids when asked to
+  // (dark_amd/_hip.py), here they are clamped so that no access leaves the table
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const TW* src = table + id * d;
+  float* dst = out + (int64_t)row * d;
+  for (int c = lane * 4; c < d; c += 256) {
+    float4 v;
+    if constexpr (sizeof(TW) == 4) {
+      v = *(const float4*)(src + c);
+    } else {
+      const bf16x4 b = *(const bf16x4*)(src + c);
+      v = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
+    }
+    *(float4*)(dst + c) = v;
+  }
+}
+
+int launch_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+                 hipStream_t st) {
+  DARK_CHECK_ARG(d % 4 == 0, "embed: d=%d must be a multiple of 4", d);
+  const dim3 grid(cdiv(M, 4)), block(256);
+  if (dtype == DARK_BF16)
+    hipLaunchKernelGGL(embed_kernel<bf16_t>, grid, block, 0, st, ids, (const bf16_t*)table, out, M, d, vocab);
+  else
+    hipLaunchKernelGGL(embed_kernel<float>, grid, block, 0, st, ids, (const float*)table, out, M, d, vocab);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+// ------------------------------------------------------------------ RMSNorm (modeling_dream_length.py:69-74)
+template <typename TOut>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ w,
+                                                      TOut* __restrict__ out,
+                                                      const int32_t* __restrict__ src_rows, int n_src,
+                                                      int M, int d, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  int64_t src = row;
+  if (src_rows) {  // clamp: a stale or uninitialised index must never leave the buffer
+    src = src_rows[row];
+    src = src < 0 ? 0 : (src >= n_src ? n_src - 1 : src);
+  }
+  const float* xr = x + src * d;
+  float ss = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 v = *(const float4*)(xr + c);
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float r = 1.0f / sqrtf(ss / (float)d + eps);
+  TOut* o = out + (int64_t)row * d;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 v = *(const float4*)(xr + c);
+    const float4 g = *(const float4*)(w + c);
+    const float y0 = g.x * (v.x * r), y1 = g.y * (v.y * r), y2 = g.z * (v.z * r), y3 = g.w * (v.w * r);
+    if constexpr (sizeof(TOut) == 4) {
+      *(float4*)(o + c) = make_float4(y0, y1, y2, y3);
+    } else {
+      bf16x4 b;
+      b[0] = (bf16_t)y0; b[1] = (bf16_t)y1; b[2] = (bf16_t)y2; b[3] = (bf16_t)y3;
+      *(bf16x4*)(o + c) = b;
+    }
+  }
+}
+
+int launch_rmsnorm(int dtype, const float* x, const float* w, void* out, const int32_t* src_rows, int n_src,
+                   int M, int d, float eps, hipStream_t st) {
+  DARK_CHECK_ARG(d % 4 == 0, "rmsnorm: d=%d must be a multiple of 4", d);
+  if (M <= 0) return DARK_OK;
+  const dim3 grid(cdiv(M, 4)), block(256);
+  if (dtype == DARK_BF16)
+    hipLaunchKernelGGL(rmsnorm_kernel<bf16_t>, grid, block, 0, st, x, w, (bf16_t*)out, src_rows, n_src, M, d, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_kernel<float>, grid, block, 0, st, x, w, (float*)out, src_rows, n_src, M, d, eps);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+// ------------------------------------------------------------------ mask rows (generation_utils.py:489, :496, :501)
+// Single workgroup stream compaction over the flattened [B*N] ids: row-major order is the order
+// `logits[mask_index]` enumerates masked positions in.
+__global__ __launch_bounds__(1024) void mask_rows_kernel(const int64_t* __restrict__ x, int total, int N,
+                                                         int64_t mask_id, int32_t* __restrict__ row_index,
+                                                         int32_t* __restrict__ src_rows,
+                                                         int32_t* __restrict__ count) {
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = (total + 1023) / 1024;
+  const int lo = min(tid * chunk, total), hi = min(lo + chunk, total);
+  int cnt = 0;
+  for (int f = lo; f < hi; ++f) cnt += (x[f] == mask_id);
+  // inclusive scan inside the wave
+  int inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  int base = 0, all = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) base += wave_tot[w];
+    all += wave_tot[w];
+  }
+  int off = base + inc - cnt;
+  for (int f = lo; f < hi; ++f) {
+    if (x[f] == mask_id) {
+      row_index[off] = f;
+      src_rows[off] = (f % N == 0) ? f : f - 1;
+      ++off;
+    }
+  }
+  if (tid == 0) *count = all;
+}
+
+int launch_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* row_index, int32_t* src_rows,
+                     int32_t* count, hipStream_t st) {
+  DARK_CHECK_ARG(B > 0 && N > 0 && (int64_t)B * N < (1ll << 30), "mask_rows: bad B=%d N=%d", B, N);
+  hipLaunchKernelGGL(mask_rows_kernel, dim3(1), dim3(1024), 0, st, x, B * N, N, mask_id, row_index, src_rows,
+                     count);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+// ------------------------------------------------------------------ commit (generation_utils.py:522-534)
+// One wave per sequence.  full_confidence = -inf except at masked positions; the k largest
+// (ties -> lower index) are transferred: x0 where masked, mask_id elsewhere (re-mask quirk).
+template <int E>  // positions per lane, N <= 64*E
+__global__ __launch_bounds__(256) void commit_kernel(int64_t* __restrict__ x, int B, int N, int64_t mask_id,
+                                                     const int32_t* __restrict__ row_index, int M,
+                                                     const float* __restrict__ conf,
+                                                     const int64_t* __restrict__ x0, int k) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  // first m with row_index[m] >= b*N (binary search; row_index is ascending)
+  const int key = b * N;
+  int lo = 0, hi = M;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (row_index[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  int m_next = lo;
+  float c[E];
+  int64_t tok[E];
+  bool msk[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = e * 64 + lane;
+    const bool valid = j < N;
+    const bool is_mask = valid && x[(int64_t)b * N + j] == mask_id;
+    const unsigned long long bal = __ballot(is_mask);
+    const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+    msk[e] = is_mask;
+    c[e] = -INFINITY;
+    tok[e] = mask_id;
+    if (is_mask) {
+      c[e] = conf[m_next + rank];
+      tok[e] = x0[m_next + rank];
+    }
+    if (!valid) c[e] = __builtin_nanf("");  // never selected, never counted
+    m_next += __popcll(bal);
+  }
+  // rank of every position in (confidence desc, index asc) order
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = e * 64 + lane;
+    int rank = 0;
+#pragma unroll
+    for (int e2 = 0; e2 < E; ++e2) {
+      for (int l2 = 0; l2 < 64; ++l2) {
+        const int j2 = e2 * 64 + l2;
+        if (j2 >= N) break;
+        const float c2 = __shfl(c[e2], l2, 64);
+        rank += (c2 > c[e]) || (c2 == c[e] && j2 < j);
+      }
+    }
+    if (j < N && rank < k) x[(int64_t)b * N + j] = msk[e] ? tok[e] : mask_id;
+  }
+}
+
+int launch_commit(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M,
+                  const float* conf, const int64_t* x0, int k, hipStream_t st) {
+  DARK_CHECK_ARG(B > 0 && N > 0 && N <= 256, "commit: N=%d must be in [1,256]", N);
+  DARK_CHECK_ARG(M >= 0 && k >= 0, "commit: bad M=%d k=%d", M, k);
+  if (k == 0) return DARK_OK;
+  if (k > N) k = N;
+  const dim3 grid(cdiv(B, 4)), block(256);
+  if (N <= 64)
+    hipLaunchKernelGGL(commit_kernel<1>, grid, block, 0, st, x, B, N, mask_id, row_index, M, conf, x0, k);
+  else if (N <= 128)
+    hipLaunchKernelGGL(commit_kernel<2>, grid, block, 0, st, x, B, N, mask_id, row_index, M, conf, x0, k);
+  else
+    hipLaunchKernelGGL(commit_kernel<4>, grid, block, 0, st, x, B, N, mask_id, row_index, M, conf, x0, k);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+}  // namespace dark

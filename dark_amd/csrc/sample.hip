@@ -1,0 +1,312 @@
+// Fused temperature / top-p / top-k / softmax / categorical draw / confidence over one logits row.
+//
+// Replaces sample_tokens (generation_utils.py:58-90), top_p_logits (:37-48) and top_k_logits
+// (:50-55): a full descending sort, a cumsum, a scatter and ~8 elementwise passes over [M,V] in the
+// reference become one workgroup per masked row with the row resident in LDS.
+//
+// Nucleus filter without a sort: the kept set of top_p_logits is the prefix of the descending order
+// up to and including the first element whose inclusive cumulative probability exceeds top_p.  That
+// element is found by a 3-level (11+11+10 bit) radix select over the order-preserving integer image
+// of the logits, where each histogram bin accumulates probability MASS in 2^-40 fixed point
+// (integer LDS atomics: order independent, hence deterministic).  Equal logits keep index order
+// (torch's CPU sort is stable).  top_k uses the same select with unit weights.
+//
+// Draw: x0 = argmax_i (p_i / psum) / q_i with q ~ Exp(1) supplied by the caller, which is the ATen
+// multinomial(1) that Categorical(probs).sample() runs; ties -> lowest index (torch argmax).
+#include "common.h"
+
+namespace dark {
+
+constexpr int ST = 512;  // threads per row (8 waves)
+constexpr int NBIN = 2048;
+#define DARK_FLT_LOWEST (-3.4028234663852886e38f)  // torch.finfo(torch.float32).min
+
+__device__ __forceinline__ uint32_t fkey(float f) {  // order-preserving float -> uint
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned long long mass_fx(float l, float mx) {
+  return (unsigned long long)(expf(l - mx) * 1099511627776.0f);  // 2^40
+}
+
+struct Scratch {
+  unsigned long long u64[8];
+  double f64[8];
+  float f32a[8], f32b[8], f32c[8];
+  int i32[8];
+  // select broadcast
+  int found, bin;
+  unsigned long long above;
+};
+
+__device__ __forceinline__ float block_max(float v, Scratch* s, int tid) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((tid & 63) == 0) s->f32a[tid >> 6] = v;
+  __syncthreads();
+  float r = s->f32a[0];
+#pragma unroll
+  for (int w = 1; w < ST / 64; ++w) r = fmaxf(r, s->f32a[w]);
+  return r;
+}
+__device__ __forceinline__ double block_sum(double v, Scratch* s, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) s->f64[tid >> 6] = v;
+  __syncthreads();
+  double r = s->f64[0];
+#pragma unroll
+  for (int w = 1; w < ST / 64; ++w) r += s->f64[w];
+  return r;
+}
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, Scratch* s, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) s->u64[tid >> 6] = v;
+  __syncthreads();
+  unsigned long long r = 0;
+#pragma unroll
+  for (int w = 0; w < ST / 64; ++w) r += s->u64[w];
+  return r;
+}
+
+// Finds the first element, in descending key order, whose inclusive cumulative weight exceeds T.
+// weight = 2^-40 fixed-point softmax mass (MASS) or 1 (count).  On success returns true with
+// *tau = its key, *above = total weight of keys strictly greater, *n_tau = multiplicity of that key.
+template <bool MASS>
+__device__ bool select_crossing(const float* row, int V, float mx, unsigned long long T,
+                                unsigned long long* hist, unsigned int* cnth, Scratch* s, int tid,
+                                uint32_t* tau, unsigned long long* above, int* n_tau) {
+  uint32_t prefix = 0;
+  int pbits = 0;
+  unsigned long long A = 0;
+  int last_bin = 0;
+  for (int level = 0; level < 3; ++level) {
+    const int bits = level < 2 ? 11 : 10;
+    const int shift = 32 - pbits - bits;
+    for (int i = tid; i < NBIN; i += ST) { hist[i] = 0; cnth[i] = 0; }
+    __syncthreads();
+    for (int i = tid; i < V; i += ST) {
+      const float l = row[i];
+      const uint32_t k = fkey(l);
+      if (pbits == 0 || (k >> (32 - pbits)) == prefix) {
+        const int dg = (k >> shift) & ((1u << bits) - 1u);
+        atomicAdd(&hist[dg], MASS ? mass_fx(l, mx) : 1ull);
+        atomicAdd(&cnth[dg], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {  // wave 0: lane L owns bins [NBIN-1-32L-31, NBIN-1-32L], scanned downwards
+      const int top = NBIN - 1 - 32 * tid;
+      unsigned long long tot = 0;
+      for (int q = 0; q < 32; ++q) tot += hist[top - q];
+      unsigned long long inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o, 64);
+        if (tid >= o) inc += t;
+      }
+      unsigned long long run = A + inc - tot;  // weight strictly above this lane's bins
+      int hit = -1;
+      unsigned long long hit_above = 0;
+      for (int q = 0; q < 32; ++q) {
+        const unsigned long long hq = hist[top - q];
+        if (hit < 0 && hq != 0 && run + hq > T) { hit = top - q; hit_above = run; }
+        run += hq;
+      }
+      const unsigned long long bal = __ballot(hit >= 0);
+      if (bal == 0) {
+        if (tid == 0) s->found = 0;
+      } else {
+        const int first = __ffsll((long long)bal) - 1;
+        if (tid == first) { s->found = 1; s->bin = hit; s->above = hit_above; }
+      }
+    }
+    __syncthreads();
+    if (!s->found) return false;
+    last_bin = s->bin;
+    A = s->above;
+    prefix = (prefix << bits) | (uint32_t)last_bin;
+    pbits += bits;
+    // hist/cnth are re-zeroed at the top of the next level after this barrier-protected read
+    if (level == 2) *n_tau = (int)cnth[last_bin];
+    __syncthreads();
+  }
+  *tau = prefix;
+  *above = A;
+  return true;
+}
+
+__global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ logits, int64_t ldl, int V,
+                                                    float temperature, float top_p, int top_k, int conf_mode,
+                                                    const float* __restrict__ noise, int64_t ldn,
+                                                    float* __restrict__ conf, int64_t* __restrict__ x0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int vp = (V + 3) & ~3;
+  float* row = (float*)smem;
+  unsigned long long* hist = (unsigned long long*)(smem + (size_t)vp * 4);
+  unsigned int* cnth = (unsigned int*)(hist + NBIN);
+  Scratch* s = (Scratch*)(cnth + NBIN);
+  const int tid = threadIdx.x;
+  const int m = blockIdx.x;
+  const float* lr = logits + (int64_t)m * ldl;
+
+  // 1. temperature (generation_utils.py:60-61) and row max
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += ST) {
+    float l = lr[i];
+    if (temperature > 0.f) l = l / temperature;
+    row[i] = l;
+    mx = fmaxf(mx, l);
+  }
+  mx = block_max(mx, s, tid);
+
+  // 2. nucleus filter (generation_utils.py:37-48)
+  if (top_p > 0.f && top_p < 1.f) {
+    unsigned long long zl = 0;
+    for (int i = tid; i < V; i += ST) zl += mass_fx(row[i], mx);
+    const unsigned long long Z = block_sum_u64(zl, s, tid);
+    const unsigned long long T = (unsigned long long)((double)top_p * (double)Z);  // floor
+    uint32_t tau;
+    unsigned long long above;
+    int n_tau;
+    if (select_crossing<true>(row, V, mx, T, hist, cnth, s, tid, &tau, &above, &n_tau)) {
+      const unsigned long long fx = mass_fx(fkey_inv(tau), mx);
+      unsigned long long t_keep = fx ? (T - above) / fx + 1ull : (unsigned long long)n_tau;
+      if (t_keep >= (unsigned long long)n_tau) {
+        for (int i = tid; i < V; i += ST)
+          if (fkey(row[i]) < tau) row[i] = DARK_FLT_LOWEST;
+      } else {
+        // some, not all, of the equal-valued boundary elements are kept: the first t_keep by index
+        const int chunk = (V + ST - 1) / ST;
+        const int lo = min(tid * chunk, V), hi = min(lo + chunk, V);
+        int c = 0;
+        for (int i = lo; i < hi; ++i) c += fkey(row[i]) == tau;
+        int inc = c;
+        const int lane = tid & 63;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += t;
+        }
+        __syncthreads();
+        if (lane == 63) s->i32[tid >> 6] = inc;
+        __syncthreads();
+        int rank = inc - c;
+        for (int w = 0; w < (tid >> 6); ++w) rank += s->i32[w];
+        for (int i = lo; i < hi; ++i) {
+          const uint32_t k = fkey(row[i]);
+          if (k < tau) row[i] = DARK_FLT_LOWEST;
+          else if (k == tau) { if ((unsigned long long)rank >= t_keep) row[i] = DARK_FLT_LOWEST; ++rank; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // 3. top-k filter (generation_utils.py:50-55): keep logits >= k-th largest value
+  if (top_k > 0 && top_k < V) {
+    uint32_t tau;
+    unsigned long long above;
+    int n_tau;
+    if (select_crossing<false>(row, V, mx, (unsigned long long)(top_k - 1), hist, cnth, s, tid, &tau, &above,
+                               &n_tau)) {
+      for (int i = tid; i < V; i += ST)
+        if (fkey(row[i]) < tau) row[i] = DARK_FLT_LOWEST;
+    }
+    __syncthreads();
+  }
+
+  // 4. softmax (generation_utils.py:66): p_i = exp(l_i - max) / Z
+  double zs = 0.0;
+  for (int i = tid; i < V; i += ST) zs += (double)expf(row[i] - mx);
+  const float Zf = (float)block_sum(zs, s, tid);
+
+  double ps = 0.0, ent = 0.0;
+  float t1 = -INFINITY, t2 = -INFINITY;  // two largest probabilities
+  float bestp = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int i = tid; i < V; i += ST) {
+    const float p = expf(row[i] - mx) / Zf;
+    ps += (double)p;
+    ent += (double)(p * logf(p + 1e-10f));
+    if (p > t1) { t2 = t1; t1 = p; } else if (p > t2) { t2 = p; }
+    if (p > bestp) { bestp = p; besti = i; }
+  }
+  const float psum = (float)block_sum(ps, s, tid);
+  const float entropy = (float)block_sum(ent, s, tid);
+
+  // 5. draw (generation_utils.py:68-75)
+  if (temperature > 0.f) {
+    const float* qr = noise + (int64_t)m * ldn;
+    bestp = -INFINITY;
+    besti = 0x7fffffff;
+    for (int i = tid; i < V; i += ST) {
+      const float p = expf(row[i] - mx) / Zf;
+      const float r = (p / psum) / qr[i];
+      if (r > bestp) { bestp = r; besti = i; }
+    }
+  }
+  // block arg-max, ties -> lowest index; merge the (top1, top2) pairs alongside
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bestp, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > bestp || (ov == bestp && oi < besti)) { bestp = ov; besti = oi; }
+    const float o1 = __shfl_xor(t1, o, 64), o2 = __shfl_xor(t2, o, 64);
+    const float n1 = fmaxf(t1, o1), n2 = fmaxf(fminf(t1, o1), fmaxf(t2, o2));
+    t1 = n1; t2 = n2;
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) {
+    s->f32a[tid >> 6] = bestp; s->i32[tid >> 6] = besti;
+    s->f32b[tid >> 6] = t1; s->f32c[tid >> 6] = t2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float bv = s->f32a[0]; int bi = s->i32[0];
+    float a1 = s->f32b[0], a2 = s->f32c[0];
+    for (int w = 1; w < ST / 64; ++w) {
+      const float ov = s->f32a[w]; const int oi = s->i32[w];
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      const float o1 = s->f32b[w], o2 = s->f32c[w];
+      const float n1 = fmaxf(a1, o1), n2 = fmaxf(fminf(a1, o1), fmaxf(a2, o2));
+      a1 = n1; a2 = n2;
+    }
+    if (bi < 0 || bi >= V) bi = 0;  // all-NaN row: keep the index in range
+    float c;
+    if (conf_mode == DARK_CONF_NEG_ENTROPY) c = entropy;
+    else if (conf_mode == DARK_CONF_MARGIN) c = a1 - a2;
+    else c = expf(row[bi] - mx) / Zf;
+    conf[m] = c;
+    x0[m] = (int64_t)bi;
+  }
+}
+
+int launch_sample(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
+                  int conf_mode, const float* noise, int64_t ldn, float* conf, int64_t* x0, hipStream_t st) {
+  if (M <= 0) return DARK_OK;
+  DARK_CHECK_ARG(V >= 2 && V <= 32768, "sample_rows: V=%d must be in [2, 32768]", V);
+  DARK_CHECK_ARG(ldl >= V, "sample_rows: ldl < V");
+  DARK_CHECK_ARG(logits && conf && x0, "sample_rows: null pointer");
+  DARK_CHECK_ARG(conf_mode >= 0 && conf_mode <= 2, "sample_rows: bad conf_mode %d", conf_mode);
+  DARK_CHECK_ARG(!(temperature > 0.f) || (noise && ldn >= V), "sample_rows: temperature > 0 needs noise [M,V]");
+  DARK_CHECK_ARG(temperature >= 0.f, "sample_rows: negative temperature");
+  const int smem = ((V + 3) & ~3) * 4 + NBIN * 8 + NBIN * 4 + (int)sizeof(Scratch);
+  static int attr_smem = 0;
+  if (smem > attr_smem) {
+    DARK_CHECK_HIP(hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_smem = smem;
+  }
+  hipLaunchKernelGGL(sample_kernel, dim3(M), dim3(ST), smem, st, logits, ldl, V, temperature, top_p, top_k,
+                     conf_mode, noise, ldn, conf, x0);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+}  // namespace dark

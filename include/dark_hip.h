@@ -1,0 +1,161 @@
+/* dark_hip.h - C ABI of the MI355X-native DARK denoise / unmask hot path.
+ *
+ * The reference (HKUST-KnowComp/DARK) is pure Python: its "FFI" for this path is
+ * the set of ATen ops that `DreamModel_length.forward` and
+ * `DreamGenerationMixin._sample` launch per denoise step.  Each entry point below
+ * replaces one group of those ops and cites the reference lines it stands in for
+ * (paths relative to the reference root).  All pointers are DEVICE pointers unless
+ * stated otherwise; `stream` is a `hipStream_t` passed as `void*` (NULL = default
+ * stream).  Every function only enqueues work on `stream`: no allocation, no
+ * synchronisation, no host copies.  Return value: DARK_OK or a DARK_ERR_* code;
+ * `dark_hip_last_error()` returns a thread-local message for the last failure.
+ *
+ * Python binding (ctypes): dark_amd/_hip.py.  INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ */
+#ifndef DARK_HIP_H_
+#define DARK_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DARK_HIP_ABI_VERSION 1
+
+#define DARK_OK 0
+#define DARK_ERR_ARG 1         /* bad shape / pointer / unsupported size */
+#define DARK_ERR_HIP 2         /* a HIP runtime call failed */
+#define DARK_ERR_UNSUPPORTED 3 /* valid request this build has no kernel for */
+
+/* arithmetic type of weights and GEMM/attention operands (accumulation is always fp32,
+ * the residual stream and logits are always fp32) */
+#define DARK_F32 0
+#define DARK_BF16 1
+
+/* confidence definitions of generation_utils.py:505-517 */
+#define DARK_CONF_PROB 0        /* probs[x0]           ('maskgit_plus', 'origin') */
+#define DARK_CONF_MARGIN 1      /* top1 - top2         ('topk_margin')            */
+#define DARK_CONF_NEG_ENTROPY 2 /* sum p*log(p+1e-10)  ('entropy')                */
+
+/* One decoder layer, packed by dark_amd/modeling_dream_length.py:pack_weights().
+ * `w_*` are row-major [out_features_padded, in_features] in the model dtype (rows padded with
+ * zeros to a multiple of 128).  Replaces the nn.Linear / DreamRMSNorm parameters of
+ * modeling_dream_length.py:270-273 (q/k/v/o), :216-218 (gate/up/down), :456-457 (norms). */
+typedef struct dark_layer_weights {
+  const void* w_qkv;   /* [3d, d]: q rows, then k rows, then v rows                        */
+  const float* b_qkv;  /* [3d] fp32                                                        */
+  const void* w_o;     /* [d, d]                                                           */
+  const void* w_gu;    /* [2ff, d]: gate/up interleaved in groups of 32 output columns:    *
+                        * rows [64g, 64g+32) = gate[32g..], rows [64g+32, 64g+64) = up[32g..] */
+  const void* w_down;  /* [d, ff]                                                          */
+  const float* ln1;    /* input_layernorm.weight [d] fp32                                  */
+  const float* ln2;    /* post_attention_layernorm.weight [d] fp32                         */
+} dark_layer_weights;
+
+/* Whole model (DreamConfig shape contract, configuration_dream.py:29-50). */
+typedef struct dark_model_desc {
+  int32_t dtype;      /* DARK_F32 | DARK_BF16 */
+  int32_t vocab;      /* V */
+  int32_t vocab_pad;  /* rows of lm_head, multiple of 128 */
+  int32_t d;          /* hidden_size, multiple of 64 */
+  int32_t ff;         /* intermediate_size, multiple of 64 */
+  int32_t n_layers;
+  int32_t n_heads;
+  int32_t head_dim;   /* 64 or 96 */
+  int32_t max_pos;    /* rows of the RoPE tables */
+  float rms_eps;
+  const void* embed;        /* [V, d] model dtype (embed_tokens, :615) */
+  const float* final_norm;  /* [d] fp32 (model.norm, :620) */
+  const void* lm_head;      /* [vocab_pad, d] model dtype, untied (:743) */
+  const float* rope_cos;    /* [max_pos, head_dim/2] fp32 (DreamRotaryEmbedding.forward, :151-171) */
+  const float* rope_sin;    /* [max_pos, head_dim/2] fp32 */
+  const dark_layer_weights* layers; /* HOST array of n_layers entries */
+} dark_model_desc;
+
+int dark_hip_abi_version(void);
+const char* dark_hip_last_error(void);
+
+/* Bytes of scratch `dark_forward_hidden` / `dark_lm_head_rows` need for the given sizes. */
+size_t dark_forward_workspace_bytes(const dark_model_desc* m, int B, int N);
+size_t dark_head_workspace_bytes(const dark_model_desc* m, int M);
+
+/* Transformer body.  Replaces DreamBaseModel.forward up to, but excluding, the final
+ * RMSNorm (modeling_dream_length.py:633-716): embedding gather, RoPE, L x [RMSNorm, QKV+bias,
+ * RoPE, bidirectional SDPA, o_proj, residual, RMSNorm, SwiGLU MLP, residual].
+ *   ids      [B,N] int64
+ *   pos      [B,N] int32 position ids, or NULL for arange(N)            (generation_utils.py:465-466)
+ *   key_mask [B,N] uint8 (1 = attend), or NULL for no masking; the pairwise mask is the outer
+ *            AND of this vector with itself, fully-masked query rows give 0 (:469-472)
+ *   hidden   [B*N, d] fp32 OUT: residual stream after the last layer (pre final norm) */
+int dark_forward_hidden(const dark_model_desc* m, const int64_t* ids, const int32_t* pos,
+                        const uint8_t* key_mask, int B, int N, void* workspace, size_t workspace_bytes,
+                        float* hidden, void* stream);
+
+/* Final RMSNorm + LM head on selected rows.  Replaces `self.norm` (:721) and `lm_head` (:809)
+ * restricted to the rows the sampler consumes, including the logit shift of
+ * generation_utils.py:496 when `src_rows` comes from dark_mask_rows.
+ *   src_rows [M] int32 row ids into `hidden`, or NULL for rows 0..M-1
+ *   logits   [M, ldl] fp32 OUT (columns >= V untouched) */
+int dark_lm_head_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M,
+                      void* workspace, size_t workspace_bytes, float* logits, int64_t ldl, void* stream);
+
+/* `mask_index = (x == mask_token_id)` + the row-major compaction `logits[mask_index]` uses
+ * (generation_utils.py:489, :501).  row_index[m] = b*N+j of the m-th masked position,
+ * src_rows[m] = b*N + max(j-1, 0) (the logit shift, :496); *count = M.  Buffers hold B*N ints. */
+int dark_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* row_index,
+                   int32_t* src_rows, int32_t* count, void* stream);
+
+/* sample_tokens (generation_utils.py:58-90) incl. top_p_logits (:37-48) and top_k_logits (:50-55).
+ *   logits [M, ldl] fp32 (read-only), V columns used
+ *   temperature: 0 => greedy (probs.max); > 0 => x0 = argmax(p_norm / noise), the ATen
+ *                multinomial(1) that Categorical.sample() runs (:70)
+ *   top_p: nucleus threshold, applied iff 0 < top_p < 1;  top_k: applied iff > 0
+ *   noise [M, ldn] fp32 Exp(1) draws (`empty_like(probs).exponential_()`), required iff temperature > 0
+ *   conf [M] fp32 OUT, x0 [M] int64 OUT */
+int dark_sample_rows(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p,
+                     int top_k, int conf_mode, const float* noise, int64_t ldn, float* conf,
+                     int64_t* x0, void* stream);
+
+/* Confidence-ranked commit (generation_utils.py:522-534 with alg_temp in {None, 0}):
+ * per row, the k positions with the largest confidence (non-masked positions count as -inf, ties
+ * go to the lower index) receive x0 if masked, mask_id otherwise (the re-mask quirk).
+ *   x [B,N] int64 IN/OUT; row_index [M] from dark_mask_rows; conf/x0 [M] from dark_sample_rows */
+int dark_commit_topk(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M,
+                     const float* conf, const int64_t* x0, int k, void* stream);
+
+/* One whole denoise step for a batch whose masked-row count M is known on the host
+ * (uniform layouts): body forward -> mask rows -> head on masked rows -> sample -> commit.
+ * Replaces one iteration of the loop at generation_utils.py:488-540 for the confidence algs.
+ *   noise [M, V] fp32 or NULL when temperature == 0;  k = number_transfer_tokens of this step
+ *   workspace: dark_step_workspace_bytes(m, B, N, M) bytes */
+size_t dark_step_workspace_bytes(const dark_model_desc* m, int B, int N, int M);
+/* Byte offsets inside the step workspace of {hidden fp32 [B*N,d], row_index i32, src_rows i32, count i32,
+ * logits fp32 [M,V], conf fp32 [M], x0 i64 [M]} so callers (hooks, parity tests) can read the
+ * intermediates that generation_utils.py:495-517 exposes as Python tensors. */
+int dark_step_workspace_offsets(const dark_model_desc* m, int B, int N, int M, size_t* out7);
+int dark_denoise_step(const dark_model_desc* m, int64_t* x, const int32_t* pos, const uint8_t* key_mask,
+                      int B, int N, int M, int64_t mask_id, float temperature, float top_p, int top_k,
+                      int conf_mode, const float* noise, int k, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* ---- unit-test hooks (no counterpart in the reference): launch ONE kernel of the path so that
+ * tests/test_hip_kernels.py can pin it against the oracle in isolation.
+ *   epi: 0 = +bias (out in model dtype), 1 = residual add into fp32 out, 2 = SwiGLU over interleaved
+ *        gate/up rows (out [M, N/2] model dtype), 3 = plain fp32 store.  W has rows padded to 128. */
+int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
+                  int N, int K, int64_t ldo, void* stream);
+int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
+                       const uint8_t* key_mask, void* out, int B, int N, int H, int HD, int max_pos,
+                       void* stream);
+int dark_dbg_rmsnorm(int dtype, const float* x, const float* w, void* out, const int32_t* src_rows,
+                     int n_src, int M, int d, float eps, void* stream);
+int dark_dbg_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DARK_HIP_H_ */

@@ -1,0 +1,297 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (libdark_hip.so) against the CPU oracle.
+
+Bars: integer outputs (token ids, row indices, committed sequences) bit-exact; fp32 kernels within
+1e-4 relative of an fp64 reference (north-star: logits within 1e-3); bf16 kernels within 2e-2 of the
+fp32 oracle (stated looser bound: bf16 has 8 mantissa bits, inputs are rounded before the MFMA).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dream_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from dark_amd import _hip
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return _hip.load()
+
+
+def _hip():
+    from dark_amd import _hip
+    return _hip
+
+
+def _s():
+    return _hip().stream_ptr(torch.device(DEV))
+
+
+def _pad_rows(w, mult=128):
+    r = (-w.shape[0]) % mult
+    return w if r == 0 else torch.cat([w, w.new_zeros((r,) + tuple(w.shape[1:]))], 0)
+
+
+def _tol(dtype):
+    return dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
+
+
+def _dt(dtype):
+    return _hip().DARK_BF16 if dtype == torch.bfloat16 else _hip().DARK_F32
+
+
+# --------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(300, 576, 192), (2944, 2304, 768), (129, 768, 3072), (64, 15080, 768)])
+def test_gemm_plain_and_bias(lib, dtype, M, N, K):
+    H = _hip()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dtype)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().t()
+    Ad, Wd = A.to(DEV), _pad_rows(W).to(DEV)
+    # epi 3: plain fp32 store with an ldo wider than N and a guard column
+    ldo = N + 5
+    out = torch.full((M, ldo), 7.0, device=DEV)
+    H.check(lib.dark_dbg_gemm(_dt(dtype), 3, H.ptr(Ad), H.ptr(Wd), None, H.ptr(out), M, N, K, ldo, _s()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out[:, :N].cpu().double().numpy(), ref.numpy(), **_tol(dtype))
+    assert bool((out[:, N:] == 7.0).all()), "columns beyond N must stay untouched"
+    # epi 0: + bias, output in the model dtype
+    out2 = torch.zeros((M, N), device=DEV, dtype=dtype)
+    bd = _pad_rows(bias).to(DEV)
+    H.check(lib.dark_dbg_gemm(_dt(dtype), 0, H.ptr(Ad), H.ptr(Wd), H.ptr(bd), H.ptr(out2), M, N, K, N, _s()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out2.cpu().double().numpy(), (ref + bias.double()).numpy(), **_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_resid_and_swiglu(lib, dtype):
+    H = _hip()
+    from dark_amd.modeling_dream_length import interleave_gate_up
+    g = torch.Generator().manual_seed(5)
+    M, d, ff = 333, 192, 384
+    A = torch.randn(M, ff, generator=g).to(dtype)
+    Wd_ = (torch.randn(d, ff, generator=g) * 0.05).to(dtype)
+    res = torch.randn(M, d, generator=g)
+    x = res.clone().to(DEV)
+    H.check(lib.dark_dbg_gemm(_dt(dtype), 1, H.ptr(A.to(DEV)), H.ptr(_pad_rows(Wd_).to(DEV)), None, H.ptr(x), M, d, ff,
+                              d, _s()))
+    torch.cuda.synchronize()
+    ref = res.double() + A.double() @ Wd_.double().t()
+    np.testing.assert_allclose(x.cpu().double().numpy(), ref.numpy(), **_tol(dtype))
+    # SwiGLU over interleaved gate/up
+    X = torch.randn(M, d, generator=g).to(dtype)
+    Wg = (torch.randn(ff, d, generator=g) * 0.1).to(dtype)
+    Wu = (torch.randn(ff, d, generator=g) * 0.1).to(dtype)
+    Wgu = _pad_rows(interleave_gate_up(Wg, Wu)).to(DEV)
+    act = torch.zeros(M, ff, device=DEV, dtype=dtype)
+    H.check(lib.dark_dbg_gemm(_dt(dtype), 2, H.ptr(X.to(DEV)), H.ptr(Wgu), None, H.ptr(act), M, 2 * ff, d, ff, _s()))
+    torch.cuda.synchronize()
+    gg, uu = X.double() @ Wg.double().t(), X.double() @ Wu.double().t()
+    ref = torch.nn.functional.silu(gg) * uu
+    np.testing.assert_allclose(act.cpu().double().numpy(), ref.numpy(), **_tol(dtype))
+
+
+# --------------------------------------------------------------------------- elementwise
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_and_rmsnorm(lib, dtype):
+    H = _hip()
+    g = torch.Generator().manual_seed(3)
+    V, d, M = 512, 192, 77
+    table = torch.randn(V, d, generator=g).to(dtype)
+    ids = torch.randint(0, V, (M,), generator=g)
+    out = torch.zeros(M, d, device=DEV)
+    H.check(lib.dark_dbg_embed(_dt(dtype), H.ptr(ids.to(DEV)), H.ptr(table.to(DEV)), H.ptr(out), M, d, V, _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), table.float()[ids])
+    x = torch.randn(M, d, generator=g) * 3
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    src = torch.randint(0, M, (40,), generator=g).int()
+    y = torch.zeros(40, d, device=DEV, dtype=dtype)
+    H.check(lib.dark_dbg_rmsnorm(_dt(dtype), H.ptr(x.to(DEV)), H.ptr(w.to(DEV)), H.ptr(y), H.ptr(src.to(DEV)), M, 40, d,
+                                 1e-6, _s()))
+    torch.cuda.synchronize()
+    ref = O.rms_norm(x[src.long()], w, 1e-6)
+    np.testing.assert_allclose(y.cpu().float().numpy(), ref.numpy(), **(_tol(dtype) if dtype == torch.bfloat16
+                                                                         else dict(rtol=2e-6, atol=1e-6)))
+
+
+# --------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,H_,HD,masked", [(46, 2, 96, False), (46, 8, 96, True), (128, 3, 64, True),
+                                             (17, 2, 64, False), (100, 2, 96, True)])
+def test_attention(lib, dtype, N, H_, HD, masked):
+    Hh = _hip()
+    from dark_amd.modeling_dream_length import rope_tables
+    g = torch.Generator().manual_seed(N * 7 + HD)
+    B, d = 3, H_ * HD
+    qkv = torch.randn(B, N, 3 * d, generator=g).to(dtype)
+    cos, sin = rope_tables(HD, 1000.0, 128)
+    key_mask = pos = None
+    am4 = None
+    pos_ids = torch.arange(N).unsqueeze(0).expand(B, -1)
+    if masked:
+        am = torch.ones(B, N, dtype=torch.long)
+        am[0, N // 3: N // 2] = 0
+        am[2, 1:4] = 0
+        pos_ids = am.cumsum(-1) - 1
+        pos_ids.masked_fill_(am == 0, 1)
+        am4 = torch.logical_and(am.unsqueeze(1).unsqueeze(-2), am.unsqueeze(1).unsqueeze(-1))
+        key_mask = am.to(torch.uint8).to(DEV)
+        pos = pos_ids.int().contiguous().to(DEV)
+    out = torch.zeros(B * N, d, device=DEV, dtype=dtype)
+    Hh.check(lib.dark_dbg_attention(_dt(dtype), Hh.ptr(qkv.to(DEV)), Hh.ptr(cos.to(DEV)), Hh.ptr(sin.to(DEV)),
+                                    Hh.ptr(pos), Hh.ptr(key_mask), Hh.ptr(out), B, N, H_, HD, 128, _s()))
+    torch.cuda.synchronize()
+    # oracle: same ops as modeling_dream_length.py:385-431 on the fp32 image of the inputs
+    q, k, v = [t.float().view(B, N, H_, HD).transpose(1, 2) for t in qkv.float().split(d, dim=-1)]
+    c, s = O.rope_cos_sin(pos_ids, HD, 1000.0)
+    q, k = O.apply_rope(q, k, c, s)
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=am4, is_causal=False)
+    ref = ref.transpose(1, 2).reshape(B * N, d)
+    ref = torch.nan_to_num(ref, nan=0.0)  # fully-masked query rows: 0
+    np.testing.assert_allclose(out.cpu().float().numpy(), ref.numpy(), **(_tol(dtype) if dtype == torch.bfloat16
+                                                                           else dict(rtol=1e-4, atol=1e-5)))
+
+
+# --------------------------------------------------------------------------- sampling
+def _sample_hip(lib, logits, T, top_p, top_k, mode, noise):
+    H = _hip()
+    M, V = logits.shape
+    conf = torch.zeros(M, device=DEV)
+    x0 = torch.zeros(M, dtype=torch.long, device=DEV)
+    ld = logits.to(DEV).contiguous()
+    nd = noise.to(DEV).contiguous() if noise is not None else None
+    H.check(lib.dark_sample_rows(H.ptr(ld), V, M, V, float(T), float(top_p or 0.0), int(top_k or 0), mode, H.ptr(nd),
+                                 V if nd is not None else 0, H.ptr(conf), H.ptr(x0), _s()))
+    torch.cuda.synchronize()
+    return conf.cpu(), x0.cpu()
+
+
+def _mode(margin, negent):
+    H = _hip()
+    return H.CONF_NEG_ENTROPY if negent else (H.CONF_MARGIN if margin else H.CONF_PROB)
+
+
+def test_sample_rows_golden_cases(lib, goldens, golden_meta):
+    """The reference's own sample_tokens outputs (tests/golden), noise replayed from the recorded seed."""
+    logits = torch.from_numpy(goldens["st_logits"])
+    for ci, c in enumerate(golden_meta["cases"]["sample_tokens"]):
+        torch.manual_seed(c["seed"])
+        noise = torch.empty_like(logits).exponential_(1) if c["T"] > 0 else None
+        conf, x0 = _sample_hip(lib, logits, c["T"], c["top_p"], c["top_k"], _mode(c["margin"], c["neg_entropy"]), noise)
+        # rows 5 (all equal) and 7 (200 exact duplicates): torch.sort's order among equal logits is
+        # unspecified, so which duplicates survive the nucleus filter is not pinned by the reference
+        keep = [r for r in range(logits.shape[0]) if r not in (5, 7)]
+        assert np.array_equal(x0.numpy()[keep], goldens[f"st{ci}_x0"][keep]), f"case {ci}"
+        np.testing.assert_allclose(conf.numpy()[keep], goldens[f"st{ci}_conf"][keep], rtol=2e-5, atol=1e-6,
+                                   err_msg=f"case {ci}")
+
+
+@pytest.mark.parametrize("T,top_p,top_k,margin,negent", [
+    (0.0, None, None, False, False), (0.1, 0.9, None, False, True), (0.5, 0.9, None, False, True),
+    (1.0, 0.95, None, True, False), (0.7, None, 50, False, True), (0.3, 0.8, 7, False, False),
+    (0.0, 0.9, None, False, True), (2.0, 0.999, None, False, True)])
+def test_sample_rows_large_vocab(lib, T, top_p, top_k, margin, negent):
+    g = torch.Generator().manual_seed(11)
+    M, V = 96, 15080
+    logits = torch.randn(M, V, generator=g) * 0.55
+    logits[::7] *= 4
+    noise = torch.empty(M, V).exponential_(1, generator=g) if T > 0 else None
+    rc, rx = O.sample_tokens(logits, temperature=T, top_p=top_p, top_k=top_k, margin_confidence=margin,
+                             neg_entropy=negent, noise=noise)
+    conf, x0 = _sample_hip(lib, logits, T, top_p, top_k, _mode(margin, negent), noise)
+    assert torch.equal(x0, rx)
+    np.testing.assert_allclose(conf.numpy(), rc.numpy(), rtol=3e-5, atol=1e-6)
+
+
+def test_sample_rows_dbpedia_vocab(lib):
+    g = torch.Generator().manual_seed(12)
+    M, V = 40, 25427
+    logits = torch.randn(M, V, generator=g)
+    noise = torch.empty(M, V).exponential_(1, generator=g)
+    rc, rx = O.sample_tokens(logits, temperature=0.5, top_p=0.9, neg_entropy=True, noise=noise)
+    conf, x0 = _sample_hip(lib, logits, 0.5, 0.9, None, _hip().CONF_NEG_ENTROPY, noise)
+    assert torch.equal(x0, rx)
+    np.testing.assert_allclose(conf.numpy(), rc.numpy(), rtol=3e-5, atol=1e-6)
+
+
+def test_sample_rows_kept_set_matches_top_p(lib):
+    """Property at full size: with noise concentrated on one token, x0 must be that token iff it survives
+    the nucleus filter of the oracle."""
+    g = torch.Generator().manual_seed(13)
+    M, V = 64, 15080
+    logits = torch.randn(M, V, generator=g)
+    filt = O.top_p_logits(logits / 0.7, 0.9)
+    kept = filt > torch.finfo(torch.float32).min
+    probe = torch.randint(0, V, (M,), generator=g)
+    noise = torch.full((M, V), 1e30)
+    noise[torch.arange(M), probe] = 1e-30
+    conf, x0 = _sample_hip(lib, logits, 0.7, 0.9, None, _hip().CONF_PROB, noise)
+    exp_hit = kept[torch.arange(M), probe]
+    assert torch.equal(x0 == probe, exp_hit)
+    assert 0 < int(exp_hit.sum()) < M  # the probe set exercises both outcomes
+
+
+# --------------------------------------------------------------------------- mask rows + commit
+def _commit_ref(x, mask_id, conf, x0, k):
+    """generation_utils.py:522-534 with ties -> lower index."""
+    x = x.clone()
+    mask_index = x == mask_id
+    full = torch.full(x.shape, -torch.inf)
+    full[mask_index] = conf
+    # stable descending sort = (confidence desc, index asc)
+    order = torch.sort(full, dim=1, descending=True, stable=True).indices[:, :k]
+    x_ = torch.zeros_like(x) + mask_id
+    x_[mask_index] = x0
+    rows = torch.arange(x.size(0)).unsqueeze(1).expand_as(order)
+    x[rows, order] = x_[rows, order]
+    return x
+
+
+@pytest.mark.parametrize("B,N,k", [(8, 46, 1), (8, 46, 3), (64, 46, 11), (5, 128, 7), (3, 200, 4)])
+def test_mask_rows_and_commit(lib, B, N, k):
+    H = _hip()
+    g = torch.Generator().manual_seed(B * N + k)
+    mask_id = 6
+    x = torch.randint(100, 500, (B, N), generator=g)
+    x[torch.rand(B, N, generator=g) < 0.3] = mask_id
+    x[0] = 7          # a row with no mask at all (re-mask quirk: k positions get MASK)
+    x[1, :] = mask_id  # a fully masked row
+    xd = x.to(DEV)
+    ri = torch.zeros(B * N, dtype=torch.int32, device=DEV)
+    sr = torch.zeros(B * N, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(4, dtype=torch.int32, device=DEV)
+    H.check(lib.dark_mask_rows(H.ptr(xd), B, N, mask_id, H.ptr(ri), H.ptr(sr), H.ptr(cnt), _s()))
+    torch.cuda.synchronize()
+    flat = (x.view(-1) == mask_id).nonzero().view(-1)
+    M = flat.numel()
+    assert int(cnt[0]) == M
+    assert torch.equal(ri[:M].cpu().long(), flat)
+    assert torch.equal(sr[:M].cpu().long(), torch.where(flat % N == 0, flat, flat - 1))
+    conf = torch.randn(M, generator=g)
+    conf = torch.round(conf * 4) / 4  # many exact ties
+    x0 = torch.randint(100, 500, (M,), generator=g)
+    H.check(lib.dark_commit_topk(H.ptr(xd), B, N, mask_id, H.ptr(ri), M, H.ptr(conf.to(DEV)), H.ptr(x0.to(DEV)), k,
+                                 _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), _commit_ref(x, mask_id, conf, x0, k))
+
+
+def test_error_paths(lib):
+    H = _hip()
+    with pytest.raises(H.DarkHipError):
+        H.check(lib.dark_sample_rows(None, 10, 1, 10, 0.0, 0.0, 0, 0, None, 0, None, None, None))
+    a = torch.zeros(4, 100, device=DEV)
+    c = torch.zeros(4, device=DEV)
+    i = torch.zeros(4, dtype=torch.long, device=DEV)
+    with pytest.raises(H.DarkHipError):  # temperature > 0 without noise
+        H.check(lib.dark_sample_rows(H.ptr(a), 100, 4, 100, 0.5, 0.9, 0, 2, None, 0, H.ptr(c), H.ptr(i), _s()))
+    with pytest.raises(H.DarkHipError):  # K not a multiple of 64
+        H.check(lib.dark_dbg_gemm(0, 3, H.ptr(a), H.ptr(a), None, H.ptr(a), 4, 4, 100, 4, _s()))

@@ -1,0 +1,218 @@
+"""GPU parity tests of the whole path behind the reference's Python surface
+(DreamModel_length.forward / diffusion_generate) against the committed reference goldens and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from dark_amd import DreamConfig, DreamGenerationConfig, DreamModel_length, DreamModelOutput, synth
+from oracle import dream_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(meta_cfg, rich, dtype=torch.float32):
+    cfg = DreamConfig(**meta_cfg)
+    m = DreamModel_length(cfg)
+    m.load_state_dict(synth.make_weights(cfg, seed=0, rich=rich), strict=True)
+    return m.to(DEV).to(dtype)
+
+
+@pytest.fixture(scope="module")
+def mini(golden_meta):
+    return _model(golden_meta["mini"], True)
+
+
+def _gc(n_in):
+    return DreamGenerationConfig(mask_token_id=synth.MASK, pad_token_id=synth.END, bos_token_id=synth.BOS,
+                                 eos_token_id=synth.END, expand_token_id=synth.EXPAND, delete_token_id=synth.END,
+                                 sep_token_id=synth.SEP, max_length=n_in + 1)
+
+
+def _cpu_noise(seed):
+    """Replays the reference's RNG stream: it draws exponential_([M,V]) from the global CPU generator once
+    per step (and rand(M) first for alg='origin')."""
+    torch.manual_seed(seed)
+    return (lambda step, M, V: torch.empty(M, V).exponential_(1)), (lambda step, M: torch.rand(M))
+
+
+def test_forward_logits_fp32(mini, goldens):
+    ids = torch.from_numpy(goldens["fwd_ids"]).to(DEV)
+    B, N = ids.shape
+    out = mini(ids, torch.ones(B, 1, N, N, dtype=torch.bool, device=DEV), torch.arange(N, device=DEV).expand(B, -1))
+    ref = goldens["fwd_logits"]
+    got = out.logits.cpu().numpy()
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-5)   # north-star bound: 1e-3 relative
+    assert np.abs(got - ref).max() < 2e-5                          # what fp32 MFMA actually achieves
+
+
+def test_forward_padded_mask_fp32(mini, goldens):
+    ids = torch.from_numpy(goldens["fwd_ids"]).to(DEV)
+    am = torch.from_numpy(goldens["fwdpad_mask"]).to(DEV)
+    tok = am.cumsum(-1) - 1
+    tok.masked_fill_(am == 0, 1)
+    m4 = torch.logical_and(am.unsqueeze(1).unsqueeze(-2), am.unsqueeze(1).unsqueeze(-1))
+    got = mini(ids, m4, tok).logits.cpu().numpy()
+    ref = goldens["fwdpad_logits"]
+    live = goldens["fwdpad_mask"].astype(bool)
+    # rows of masked-out queries: the reference's value there depends on SDPA's all-masked-row handling and is
+    # never consumed (those positions are padding); compare the live rows
+    np.testing.assert_allclose(got[live], ref[live], rtol=1e-3, atol=2e-5)
+
+
+def test_forward_bf16(golden_meta, goldens):
+    m = _model(golden_meta["mini"], True, torch.bfloat16)
+    ids = torch.from_numpy(goldens["fwd_ids"]).to(DEV)
+    got = m(ids).logits.float().cpu().numpy()
+    ref = goldens["fwd_logits"]
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 3e-2, err  # stated bf16 bound: 3% of the logit range
+
+
+def _loop_ids(case, goldens):
+    if "ids" in case:
+        return torch.from_numpy(goldens[case["ids"]])
+    return torch.from_numpy(goldens["loop_abd_ids" if case["name"].startswith("abd") else "loop_ded_ids"])
+
+
+def test_loops_match_reference_goldens(mini, goldens, golden_meta):
+    """Token ids and unmask order after every step == the reference's own run (fp32, recorded seed)."""
+    checked = 0
+    for case in golden_meta["cases"]["loops"]:
+        name, kw = case["name"], dict(case["kw"])
+        if name == "ded_algtemp":
+            continue  # alg_temp > 0 draws torch.multinomial from the device generator: covered by a property test
+        ids = _loop_ids(case, goldens).to(DEV)
+        am = torch.from_numpy(goldens[case["attention_mask"]]).to(DEV) if "attention_mask" in case else None
+        noise_fn, rand_fn = _cpu_noise(case["seed"])
+        extra = dict(attention_mask=am) if am is not None else {}
+        out = mini.diffusion_generate(inputs=ids, generation_config=_gc(ids.shape[1]), return_dict_in_generate=True,
+                                      output_history=True, number_transfer_tokens=1, _noise_fn=noise_fn,
+                                      _rand_fn=rand_fn, **extra, **kw)
+        assert isinstance(out, DreamModelOutput)
+        hist = torch.stack(out.history).cpu().numpy()
+        ref = goldens[name + "_hist"]
+        assert hist.shape == ref.shape, name
+        assert np.array_equal(hist, ref), f"{name}: first differing step {np.argwhere((hist != ref).any((1, 2)))[:1]}"
+        assert torch.equal(out.sequences.cpu(), torch.from_numpy(ref[-1]))
+        checked += 1
+    assert checked >= 11
+
+
+def test_alg_temp_property(mini, goldens):
+    ids = torch.from_numpy(goldens["loop_ded_ids"]).to(DEV)
+    torch.manual_seed(0)
+    out = mini.diffusion_generate(inputs=ids, generation_config=_gc(45), return_dict_in_generate=True,
+                                  output_history=True, steps=10, temperature=0.3, alg="entropy", alg_temp=0.5,
+                                  top_p=0.9)
+    sched = O.transfer_schedule(33, 10)
+    left = 33
+    for h, k in zip(out.history, sched):
+        left -= k
+        cnt = (h == synth.MASK).sum(1).cpu()
+        assert bool((cnt >= left).all()) and bool((cnt <= left + 2).all())  # +: a sampled id may equal MASK
+
+
+def test_real_shape_history_fp32(goldens, golden_meta):
+    m = _model(golden_meta["real"], False)
+    ids = torch.from_numpy(goldens["real_abd_ids"]).to(DEV)
+    x = torch.nn.functional.pad(ids, (0, 1), value=synth.MASK)
+    lg = m(x[:1]).logits[0, :3].cpu().numpy()
+    ref = goldens["real_logits_row0_pos0_3"]
+    np.testing.assert_allclose(lg, ref, rtol=1e-3, atol=5e-5)
+    for name, seed, kw in [("real_abd_t01_hist", 2, dict(steps=16, temperature=0.1, alg="entropy", alg_temp=0, top_p=0.9)),
+                           ("real_abd_greedy_hist", 2, dict(steps=8, temperature=0.0, alg="entropy", alg_temp=0, top_p=0.9))]:
+        noise_fn, _ = _cpu_noise(seed)
+        out = m.diffusion_generate(inputs=ids, generation_config=_gc(45), return_dict_in_generate=True,
+                                   output_history=True, _noise_fn=noise_fn, **kw)
+        assert np.array_equal(torch.stack(out.history).cpu().numpy(), goldens[name]), name
+
+
+def test_config1_batch64_vs_oracle(golden_meta):
+    """BASELINE config 1 shape (B=64, 16 steps, T=0.1, top_p=0.9) on a 2-layer cut of the real width, against the
+    oracle run on the same weights and the same noise: histories identical, per-step confidences close."""
+    kw = dict(golden_meta["real"], num_hidden_layers=2)
+    m = _model(kw, False)
+    cfg = O.OracleConfig(**{k: v for k, v in kw.items() if k in O.OracleConfig.__dataclass_fields__})
+    w = synth.make_weights(m.config, seed=0, rich=False)
+    ids = synth.make_inputs(64, "abd", seed=1)
+    g = torch.Generator().manual_seed(99)
+    noises = {}
+
+    def noise_fn(step, M, V):
+        if step not in noises:
+            noises[step] = torch.empty(M, V).exponential_(1, generator=g)
+        return noises[step]
+
+    trace = {}
+    out = m.diffusion_generate(inputs=ids.to(DEV), generation_config=_gc(45), return_dict_in_generate=True,
+                               output_history=True, steps=16, temperature=0.1, alg="entropy", alg_temp=0, top_p=0.9,
+                               _noise_fn=noise_fn, _trace=trace)
+    otr = O.SampleTrace()
+    seq, hist = O.sample_loop(w, cfg, ids, max_length=46, steps=16, mask_token_id=synth.MASK, alg="entropy", alg_temp=0,
+                              temperature=0.1, top_p=0.9, noise_fn=lambda s, M, V: noises[s], trace=otr)
+    assert trace["k"] == otr.k == O.transfer_schedule(11, 16)
+    for i in range(16):
+        assert torch.equal(trace["x0"][i].cpu(), otr.x0[i]), f"x0 differs at step {i}"
+        np.testing.assert_allclose(trace["confidence"][i].cpu().numpy(), otr.confidence[i].numpy(), rtol=1e-3, atol=1e-5)
+        assert torch.equal(out.history[i].cpu(), hist[i]), f"history differs at step {i}"
+
+
+def test_bf16_decisions_close_to_fp32(golden_meta):
+    """Stated bf16 bound: same schedule, and >= 90% of committed tokens equal the fp32 run under identical noise."""
+    kw = dict(golden_meta["real"], num_hidden_layers=2)
+    ids = synth.make_inputs(32, "ded", seed=3).to(DEV)
+    outs = []
+    for dt in (torch.float32, torch.bfloat16):
+        m = _model(kw, False, dt)
+        g = torch.Generator().manual_seed(5)
+        out = m.diffusion_generate(inputs=ids, generation_config=_gc(45), steps=8, temperature=0.1, alg="entropy",
+                                   alg_temp=0, top_p=0.9, _noise_fn=lambda s, M, V: torch.empty(M, V).exponential_(1, generator=g))
+        outs.append(out.cpu())
+        del m
+    assert outs[0].shape == outs[1].shape == (32, 46)
+    assert not bool((outs[1] == synth.MASK).any()) or bool((outs[0] == synth.MASK).any())
+    agree = (outs[0] == outs[1]).float().mean().item()
+    assert agree > 0.9, agree
+
+
+def test_api_contract(mini, goldens):
+    ids = torch.from_numpy(goldens["loop_abd_ids"]).to(DEV)
+    before = ids.clone()
+    # bare tensor by default (generation_utils.py:547-548), input not mutated, unknown kwargs ignored
+    seq = mini.diffusion_generate(ids, generation_config=_gc(45), steps=4, alg="entropy", number_transfer_tokens=1)
+    assert isinstance(seq, torch.Tensor) and seq.shape == (8, 46) and seq.dtype == torch.long and seq.is_cuda
+    assert torch.equal(ids, before)
+    with pytest.raises(ValueError):      # input length >= max_length (:186-192)
+        mini.diffusion_generate(ids, generation_config=_gc(44), steps=2, alg="entropy")
+    with pytest.raises(RuntimeError):    # unknown alg (:518-519)
+        mini.diffusion_generate(ids, generation_config=_gc(45), steps=2, alg="nope")
+    with pytest.raises(AssertionError):  # inputs is None (:313)
+        mini.diffusion_generate(None, generation_config=_gc(45))
+    # num_return_sequences expands the batch (:352-356); hooks are called with (None, x, None) then per step
+    calls = []
+
+    def tok_hook(step, x, logits):
+        calls.append((step, None if logits is None else tuple(logits.shape)))
+        return x
+
+    out = mini.diffusion_generate(ids[:2], generation_config=_gc(45), steps=3, alg="entropy", temperature=0.2,
+                                  num_return_sequences=2, return_dict_in_generate=True, output_history=True,
+                                  generation_tokens_hook_func=tok_hook,
+                                  generation_logits_hook_func=lambda step, x, logits: logits)
+    assert out.sequences.shape == (4, 46) and len(out.history) == 3
+    assert calls[0] == (None, None) and calls[1] == (0, (4, 46, 512)) and len(calls) == 4
+    # max_new_tokens path
+    seq = mini.diffusion_generate(ids[:2], generation_config=DreamGenerationConfig(mask_token_id=synth.MASK),
+                                  max_new_tokens=3, steps=2, alg="maskgit_plus")
+    assert seq.shape == (2, 48)
+
+
+def test_save_and_from_pretrained_roundtrip(mini, tmp_path, goldens):
+    mini.generation_config = _gc(45)
+    mini.save_pretrained(str(tmp_path))
+    m2 = DreamModel_length.from_pretrained(str(tmp_path)).to(DEV)
+    assert m2.generation_config.mask_token_id == synth.MASK and m2.generation_config.max_length == 46
+    ids = torch.from_numpy(goldens["fwd_ids"]).to(DEV)
+    assert torch.equal(m2(ids).logits, mini(ids).logits)
