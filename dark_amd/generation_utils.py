@@ -175,6 +175,7 @@ class DreamGenerationMixin:
         noise_fn = kwargs.pop("_noise_fn", None)  # parity tests: inject the Exp(1) draws
         self._rand_fn = kwargs.pop("_rand_fn", None)  # parity tests: inject alg='origin' uniforms
         trace = kwargs.pop("_trace", None)        # parity tests: dict receiving per-step k / conf / x0
+        self._state_hook = kwargs.pop("_state_hook", None)  # parity tests: teacher forcing, (step, x) -> x
 
         assert inputs is not None
         input_ids = inputs
@@ -260,6 +261,8 @@ class DreamGenerationMixin:
                 x = self._step_general(st, x, pos, key_mask, mask_token_id, temperature, top_p_f, top_k_i, alg,
                                        alg_temp, t, s, last, i, tokens_hook, logits_hook, noise_fn,
                                        trace).contiguous()
+            if getattr(self, "_state_hook", None) is not None:
+                x.copy_(self._state_hook(i, x).to(x.device))
             if histories is not None:
                 histories.append(x.clone())
 

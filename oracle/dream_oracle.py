@@ -238,12 +238,18 @@ def sample_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
                 logits_hook: Callable = lambda step, x, logits: logits,
                 noise_fn: Optional[Callable[[int, int, int], torch.Tensor]] = None,
                 trace: Optional[SampleTrace] = None, keep_logits: bool = False,
-                forward_fn: Optional[Callable] = None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                forward_fn: Optional[Callable] = None, rand_fn: Optional[Callable[[int, int], torch.Tensor]] = None,
+                tie_break: str = "torch") -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """generation_utils.py:435-548.  Returns (sequences, history) with history[i] = x after step i.
 
     ``noise_fn(step, M, V)`` injects the exponential noise of the categorical draw
     (default: drawn from torch's global CPU generator exactly where the reference draws it).
     ``forward_fn(x, attn4d, tok_idx) -> logits`` overrides the model (used to time stages).
+    ``tie_break``: which of several EXACTLY equal confidences `torch.topk` (:526) transfers is not defined
+    by the reference, it is whatever topk does on the device it runs on.  "torch" calls torch.topk here
+    (CPU: an nth_element order; this is what the CPU goldens hold).  "index" takes the lowest index among
+    equals, which is what ATen's CUDA/HIP topk (radix select, then an in-order gather of the values equal to
+    the k-th) returns and what the HIP kernel implements.  The two differ only at exact ties on the k-th value.
     """
     x = F.pad(input_ids, (0, max_length - input_ids.shape[1]), value=mask_token_id)
     if attention_mask is not None and torch.any(attention_mask == 0.0):
@@ -268,7 +274,7 @@ def sample_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
         if alg == "origin":
             p_transfer = 1 - s / t if i < steps - 1 else 1
             x0 = torch.zeros_like(x[mask_index], dtype=torch.long) + mask_token_id
-            transfer = torch.rand(*x0.shape) < p_transfer
+            transfer = (torch.rand(*x0.shape) if rand_fn is None else rand_fn(i, x0.shape[0])) < p_transfer
             sel = mask_logits[transfer]
             nz = noise_fn(i, sel.shape[0], sel.shape[1]) if (noise_fn and temperature > 0) else None
             _, x0[transfer] = sample_tokens(sel, temperature=temperature, top_p=top_p, top_k=top_k, noise=nz)
@@ -297,7 +303,10 @@ def sample_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
             full_conf[mask_index] = confidence
             if k > 0:
                 if alg_temp is None or alg_temp == 0:
-                    _, transfer_index = torch.topk(full_conf, k)
+                    if tie_break == "index":
+                        transfer_index = torch.sort(full_conf, dim=1, descending=True, stable=True).indices[:, :k]
+                    else:
+                        _, transfer_index = torch.topk(full_conf, k)
                 else:
                     full_conf = F.softmax(full_conf / alg_temp, dim=-1)
                     transfer_index = torch.multinomial(full_conf, num_samples=k)

@@ -80,8 +80,8 @@ def test_gemm_resid_and_swiglu(lib, dtype):
     Wd_ = (torch.randn(d, ff, generator=g) * 0.05).to(dtype)
     res = torch.randn(M, d, generator=g)
     x = res.clone().to(DEV)
-    H.check(lib.dark_dbg_gemm(_dt(dtype), 1, H.ptr(A.to(DEV)), H.ptr(_pad_rows(Wd_).to(DEV)), None, H.ptr(x), M, d, ff,
-                              d, _s()))
+    Ad, Wdd = A.to(DEV), _pad_rows(Wd_).to(DEV)  # keep device tensors alive across the async launch
+    H.check(lib.dark_dbg_gemm(_dt(dtype), 1, H.ptr(Ad), H.ptr(Wdd), None, H.ptr(x), M, d, ff, d, _s()))
     torch.cuda.synchronize()
     ref = res.double() + A.double() @ Wd_.double().t()
     np.testing.assert_allclose(x.cpu().double().numpy(), ref.numpy(), **_tol(dtype))
@@ -91,7 +91,8 @@ def test_gemm_resid_and_swiglu(lib, dtype):
     Wu = (torch.randn(ff, d, generator=g) * 0.1).to(dtype)
     Wgu = _pad_rows(interleave_gate_up(Wg, Wu)).to(DEV)
     act = torch.zeros(M, ff, device=DEV, dtype=dtype)
-    H.check(lib.dark_dbg_gemm(_dt(dtype), 2, H.ptr(X.to(DEV)), H.ptr(Wgu), None, H.ptr(act), M, 2 * ff, d, ff, _s()))
+    Xd = X.to(DEV)
+    H.check(lib.dark_dbg_gemm(_dt(dtype), 2, H.ptr(Xd), H.ptr(Wgu), None, H.ptr(act), M, 2 * ff, d, ff, _s()))
     torch.cuda.synchronize()
     gg, uu = X.double() @ Wg.double().t(), X.double() @ Wu.double().t()
     ref = torch.nn.functional.silu(gg) * uu
@@ -107,15 +108,16 @@ def test_embed_and_rmsnorm(lib, dtype):
     table = torch.randn(V, d, generator=g).to(dtype)
     ids = torch.randint(0, V, (M,), generator=g)
     out = torch.zeros(M, d, device=DEV)
-    H.check(lib.dark_dbg_embed(_dt(dtype), H.ptr(ids.to(DEV)), H.ptr(table.to(DEV)), H.ptr(out), M, d, V, _s()))
+    idd, tabd = ids.to(DEV), table.to(DEV)
+    H.check(lib.dark_dbg_embed(_dt(dtype), H.ptr(idd), H.ptr(tabd), H.ptr(out), M, d, V, _s()))
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), table.float()[ids])
     x = torch.randn(M, d, generator=g) * 3
     w = 1 + 0.1 * torch.randn(d, generator=g)
     src = torch.randint(0, M, (40,), generator=g).int()
     y = torch.zeros(40, d, device=DEV, dtype=dtype)
-    H.check(lib.dark_dbg_rmsnorm(_dt(dtype), H.ptr(x.to(DEV)), H.ptr(w.to(DEV)), H.ptr(y), H.ptr(src.to(DEV)), M, 40, d,
-                                 1e-6, _s()))
+    xd, wd, srcd = x.to(DEV), w.to(DEV), src.to(DEV)
+    H.check(lib.dark_dbg_rmsnorm(_dt(dtype), H.ptr(xd), H.ptr(wd), H.ptr(y), H.ptr(srcd), M, 40, d, 1e-6, _s()))
     torch.cuda.synchronize()
     ref = O.rms_norm(x[src.long()], w, 1e-6)
     np.testing.assert_allclose(y.cpu().float().numpy(), ref.numpy(), **(_tol(dtype) if dtype == torch.bfloat16
@@ -146,7 +148,8 @@ def test_attention(lib, dtype, N, H_, HD, masked):
         key_mask = am.to(torch.uint8).to(DEV)
         pos = pos_ids.int().contiguous().to(DEV)
     out = torch.zeros(B * N, d, device=DEV, dtype=dtype)
-    Hh.check(lib.dark_dbg_attention(_dt(dtype), Hh.ptr(qkv.to(DEV)), Hh.ptr(cos.to(DEV)), Hh.ptr(sin.to(DEV)),
+    qd, cd, sd = qkv.to(DEV), cos.to(DEV), sin.to(DEV)
+    Hh.check(lib.dark_dbg_attention(_dt(dtype), Hh.ptr(qd), Hh.ptr(cd), Hh.ptr(sd),
                                     Hh.ptr(pos), Hh.ptr(key_mask), Hh.ptr(out), B, N, H_, HD, 128, _s()))
     torch.cuda.synchronize()
     # oracle: same ops as modeling_dream_length.py:385-431 on the fp32 image of the inputs
@@ -278,8 +281,8 @@ def test_mask_rows_and_commit(lib, B, N, k):
     conf = torch.randn(M, generator=g)
     conf = torch.round(conf * 4) / 4  # many exact ties
     x0 = torch.randint(100, 500, (M,), generator=g)
-    H.check(lib.dark_commit_topk(H.ptr(xd), B, N, mask_id, H.ptr(ri), M, H.ptr(conf.to(DEV)), H.ptr(x0.to(DEV)), k,
-                                 _s()))
+    cd, x0d = conf.to(DEV), x0.to(DEV)
+    H.check(lib.dark_commit_topk(H.ptr(xd), B, N, mask_id, H.ptr(ri), M, H.ptr(cd), H.ptr(x0d), k, _s()))
     torch.cuda.synchronize()
     assert torch.equal(xd.cpu(), _commit_ref(x, mask_id, conf, x0, k))
 
