@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoised KG query sequences / second (BASELINE.json `metric`).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One bench "step" = one pass of the hot path over one batch: BASELINE config 2, the FB15k-237 mixed
+deductive+abductive evaluation batch of 1024 sequences per GPU (512 abduction rows with 11 masks + 512 deduction
+rows with 33 masks, as two `diffusion_generate` calls -- the reference never mixes layouts in one call,
+custom_grpo2.py:593-599), 32 denoise steps each, temperature 0.1, top_p 0.9, alg 'entropy' (main.py:393-404),
+bf16 weights/activations with fp32 accumulation, default model shape (10 x d768 x ff3072, V = 15080).
+Every denoise step runs its full forward + head + sampling; nothing is cached or skipped.
+Inputs are synthetic (dark_amd.synth), resident in HBM before the timed region; weights are random-init.
+Multi-GPU: rows are sharded data-parallel (weak scaling: 1024 sequences per GPU), no collective inside the loop;
+the per-batch result gather (sequences, fixed-width records) over RCCL is inside the timed region.
+
+The JSON line also carries
+  roofline:     the dominant kernel (gate/up GEMM with fused SwiGLU, 50% of the forward FLOPs), timed live with
+                HIP events on the launch stream (dark_prof_* hook of the C ABI) during the timed region;
+  cpu_baseline: the CPU oracle (oracle/dream_oracle.py, a PyTorch-CPU fp32 restatement of the reference path;
+                kind "port") on a bounded sample of the same workload, on this box's host cores (rank 0, N=1).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3    # fp32 matrix
+
+
+def algorithmic_flops_per_call(cfg, B, N, steps, masks_per_row):
+    """F_body(N) = N*L*(8d^2 + 6*d*ff + 4*N*d) per sequence-step, F_head = 2*d*V per masked row."""
+    from dark_amd.generation_utils import transfer_count
+    d, ff, L, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.vocab_size
+    body = N * L * (8 * d * d + 6 * d * ff + 4 * N * d)
+    ts = torch.linspace(1, 1e-3, steps + 1)
+    left, head_rows = masks_per_row, 0
+    for i in range(steps):
+        head_rows += left
+        left -= transfer_count(left, 1, ts[i], ts[i + 1], i == steps - 1)
+    return B * (steps * body + head_rows * 2 * d * V)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1024, help="sequences per GPU per step (half abd, half ded)")
+    ap.add_argument("--denoise-steps", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="sequences in the CPU-oracle sample")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dark_amd import DreamConfig, DreamGenerationConfig, DreamModel_length, _hip, dispatch, synth
+
+    lib = _hip.load()
+    cfg = DreamConfig(vocab_size=synth.vocab_size(**synth.FB15K237), mask_token_id=synth.MASK,
+                      pad_token_id=synth.END)
+    weights = synth.make_weights(cfg, seed=0)
+    model = DreamModel_length(cfg)
+    model.load_state_dict(weights, strict=True)
+    tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = model.to(dev).to(tdt)
+
+    half = args.batch // 2
+    ids_abd = synth.make_inputs(half, "abd", seed=1 + 2 * rank).to(dev)
+    ids_ded = synth.make_inputs(args.batch - half, "ded", seed=2 + 2 * rank).to(dev)
+    gc = DreamGenerationConfig(mask_token_id=synth.MASK, pad_token_id=synth.END, bos_token_id=synth.BOS,
+                               eos_token_id=synth.END, sep_token_id=synth.SEP, max_length=46)
+    gen_kw = dict(steps=args.denoise_steps, temperature=0.1, alg="entropy", alg_temp=0, top_p=0.9,
+                  number_transfer_tokens=1)
+    torch.manual_seed(2 + rank)
+
+    import warnings
+    warnings.filterwarnings("ignore", message="Padding was detected")
+
+    def one_step():
+        seqs = []
+        for ids in (ids_abd, ids_ded):
+            seqs.append(model.diffusion_generate(ids, generation_config=gc, **gen_kw))
+        out = torch.cat(seqs, 0)
+        if world > 1:  # per-batch result gather (replaces all_gather_object of mdm_unify.py:436-438)
+            out = dispatch.gather_rows(out, out.shape[0] * world)
+        return out
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = one_step()
+    fence()
+    EPI_SWIGLU = 2
+    lib.dark_prof_select_gemm(EPI_SWIGLU)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    ms, fl, n = C.c_double(), C.c_double(), C.c_int()
+    _hip.check(lib.dark_prof_read(C.byref(ms), C.byref(fl), C.byref(n)))
+    lib.dark_prof_select_gemm(-1)
+    assert out.shape == (args.batch * world, 46) and int((out[:, 0] != synth.BOS).sum()) == 0
+
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    seq_per_s = args.batch * world * args.steps / dt
+
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+    alg_flops = (algorithmic_flops_per_call(cfg, half, 46, args.denoise_steps, 11)
+                 + algorithmic_flops_per_call(cfg, args.batch - half, 46, args.denoise_steps, 33))
+    achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    result = {
+        "metric": "denoised KG query sequences/sec (whole node) at T steps",
+        "value": round(seq_per_s, 2), "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: FB15k-237 mixed deductive+abductive eval, default DARK shape "
+                               "(10L d768 ff3072 H8, V=15080, N=46)",
+                   "batch_per_gpu": args.batch, "denoise_steps": args.denoise_steps, "temperature": 0.1,
+                   "top_p": 0.9, "alg": "entropy", "parallelism": f"dp{world}", "weights": "random-init"},
+        "forward_mfma_frac": round(alg_flops * args.steps * world / dt / 1e12 / (peak * world), 4),
+        "roofline": {"bound": "mfma", "kernel": f"gemm_{args.dtype}_kernel<EPI_SWIGLU> (gate/up projection, "
+                                                "M=B*N/2 rows per call, N=6144, K=768)",
+                     "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": None, "launches": n.value,
+                     "avg_launch_ms": round(ms.value / max(n.value, 1), 4)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, weights, args, synth)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, weights, args, synth):
+    """The oracle on a bounded sample of the same workload: `cpu_sample` sequences (half abd, half ded), all
+    denoise steps, fp32, torch's intra-op threads as configured on this box."""
+    from oracle import dream_oracle as O  # baseline leg only; never on the product path
+    ocfg = O.OracleConfig(**{k: getattr(cfg, k) for k in O.OracleConfig.__dataclass_fields__})
+    n = max(2, args.cpu_sample)
+    threads = torch.get_num_threads()
+    torch.manual_seed(2)
+    t0 = time.perf_counter()
+    for kind, rows in (("abd", n // 2), ("ded", n - n // 2)):
+        ids = synth.make_inputs(rows, kind, seed=1)
+        O.sample_loop(weights, ocfg, ids, max_length=46, steps=args.denoise_steps, mask_token_id=synth.MASK,
+                      alg="entropy", alg_temp=0, temperature=0.1, top_p=0.9)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "sequences/s", "cores": threads, "kind": "port",
+            "sample": f"{n} sequences ({n // 2} abd + {n - n // 2} ded) x {args.denoise_steps} denoise steps, fp32 "
+                      f"PyTorch-CPU oracle, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,8 @@ SIGNATURES = {
     "dark_denoise_step": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dark_prof_select_gemm": (C.c_int, [C.c_int]),
+    "dark_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dark_dbg_gemm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                 C.c_int, C.c_int64, C.c_void_p]),
     "dark_dbg_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

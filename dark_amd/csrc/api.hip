@@ -205,6 +205,12 @@ int dark_denoise_step(const dark_model_desc* m, int64_t* x, const int32_t* pos, 
   return DARK_OK;
 }
 
+int dark_prof_select_gemm(int epi) { return prof_select(epi); }
+int dark_prof_read(double* total_ms, double* total_flops, int* launches) {
+  DARK_CHECK_ARG(total_ms && total_flops && launches, "prof_read: null pointer");
+  return prof_read(total_ms, total_flops, launches);
+}
+
 // ---- unit-test hooks: single-kernel launches (tests/test_hip_kernels.py) ----
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                   int64_t ldo, void* stream) {

@@ -107,6 +107,9 @@ enum Epi { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_F32 = 3 };
 int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out,
                 int M, int N, int K, int64_t ldo, hipStream_t st);
 
+int prof_select(int epi);
+int prof_read(double* total_ms, double* total_flops, int* launches);
+
 int launch_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
                  hipStream_t st);
 // out[m] = w * (x[src(m)] * rsqrt(mean(x^2) + eps)); src_rows nullable (identity), else clamped to [0,n_src)

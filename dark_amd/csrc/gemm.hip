@@ -9,6 +9,9 @@
 //         (chunk ^= row & 7) so the ds_read_b128 fragment reads spread over the bank row.
 //   fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, k ascending), BK = 16, LDS rows padded to 17.
 // Double-buffered LDS, global loads of tile t+1 issued before the MFMAs of tile t (register staging).
+#include <utility>
+#include <vector>
+
 #include "common.h"
 
 namespace dark {
@@ -257,8 +260,62 @@ static int launch_epi(int dtype, const void* A, const void* W, const float* bias
   return DARK_OK;
 }
 
+// ---- optional HIP-event timing of one GEMM flavour (bench.py roofline leg) ----
+namespace {
+struct Prof {
+  int epi = -1;  // -1: off
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  size_t used = 0;
+  double flops = 0.0;
+} g_prof;
+}  // namespace
+
+int prof_select(int epi) {
+  g_prof.epi = epi;
+  g_prof.used = 0;
+  g_prof.flops = 0.0;
+  return DARK_OK;
+}
+
+int prof_read(double* total_ms, double* total_flops, int* launches) {
+  double ms = 0.0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    DARK_CHECK_HIP(hipEventSynchronize(g_prof.ev[i].second));
+    float t = 0.f;
+    DARK_CHECK_HIP(hipEventElapsedTime(&t, g_prof.ev[i].first, g_prof.ev[i].second));
+    ms += t;
+  }
+  *total_ms = ms;
+  *total_flops = g_prof.flops;
+  *launches = (int)g_prof.used;
+  g_prof.used = 0;
+  g_prof.flops = 0.0;
+  return DARK_OK;
+}
+
+static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
+                            int N, int K, int64_t ldo, hipStream_t st);
+
 int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                 int N, int K, int64_t ldo, hipStream_t st) {
+  if (g_prof.epi != epi || g_prof.used >= 8192) return launch_gemm_impl(dtype, epi, A, W, bias, out, M, N, K, ldo, st);
+  if (g_prof.used == g_prof.ev.size()) {
+    hipEvent_t a, b;
+    DARK_CHECK_HIP(hipEventCreate(&a));
+    DARK_CHECK_HIP(hipEventCreate(&b));
+    g_prof.ev.emplace_back(a, b);
+  }
+  auto& e = g_prof.ev[g_prof.used];
+  DARK_CHECK_HIP(hipEventRecord(e.first, st));
+  const int rc = launch_gemm_impl(dtype, epi, A, W, bias, out, M, N, K, ldo, st);
+  DARK_CHECK_HIP(hipEventRecord(e.second, st));
+  g_prof.used++;
+  g_prof.flops += 2.0 * M * (double)N * K;
+  return rc;
+}
+
+static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
+                            int N, int K, int64_t ldo, hipStream_t st) {
   DARK_CHECK_ARG(dtype == DARK_F32 || dtype == DARK_BF16, "gemm: bad dtype %d", dtype);
   DARK_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   DARK_CHECK_ARG(K % 64 == 0, "gemm: K=%d must be a multiple of 64", K);

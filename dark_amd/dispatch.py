@@ -1,0 +1,117 @@
+"""Multi-GPU batch dispatcher for the denoise path: one process per GPU, rows sharded, no exchange
+inside the loop.
+
+Sequences are independent (attention is within a row, sampling per masked row, top-k per row), so a batch
+is partitioned into contiguous row blocks, one per rank, with replicated weights.  The reference does the
+same for its legacy multi-GPU evaluation (``accelerator.prepare(model, dataloader)`` shards the batches,
+``mdm_unify.py:328-331``) and gathers only results: pickled per-sample score dicts with
+``dist.all_gather_object`` and ``accelerator.gather(pattern_id)`` (``mdm_unify.py:434-438``).  Here the
+gather is ONE ``all_gather`` of fixed-width records (RCCL over xGMI when the backend is ``nccl``; ``gloo``
+in the CPU tests) -- no pickling, no per-sample objects.
+
+The single global coupling of the loop is the transfer count ``k``, computed from the BATCH-average mask
+count (``generation_utils.py:520-521``).  For the fixed layouts every row has the same number of masks and
+shards agree by construction; for ragged inputs ``global_mask_count`` all-reduces the count (8 bytes per
+step) so that a sharded run takes the same ``k`` as an unsharded one.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row block of `rank`: sizes differ by at most one, larger blocks first."""
+    if world <= 0 or not 0 <= rank < world:
+        raise ValueError(f"bad rank {rank} / world {world}")
+    q, r = divmod(total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def _world(group) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def gather_rows(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """all_gather of row blocks produced by `shard_bounds` -> the `[total, ...]` tensor on every rank.
+    Blocks are padded to the largest block so that one fixed-size collective moves everything."""
+    world, rank = _world(group)
+    if world == 1:
+        return local
+    lo, hi = shard_bounds(total, world, rank)
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} rows, shard is {hi - lo}")
+    width = -(-total // world)
+    buf = local.new_zeros((width,) + tuple(local.shape[1:]))
+    buf[: hi - lo] = local
+    out = local.new_empty((world * width,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
+    parts = []
+    for r in range(world):
+        a, b = shard_bounds(total, world, r)
+        parts.append(out[r * width: r * width + (b - a)])
+    return torch.cat(parts, dim=0)
+
+
+def gather_metric_records(scores: torch.Tensor, pattern_id: torch.Tensor, total: int, group=None
+                          ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fixed-width replacement for ``all_gather_object(scores)`` + ``gather(pattern_id)``
+    (mdm_unify.py:434-438): scores float32 ``[B_local, F]`` (F <= 8 metric columns: smatch, jaccard, ...),
+    pattern_id int32 ``[B_local]``; both travel in one float32 record of width F+1."""
+    if scores.dim() != 2 or pattern_id.shape != scores.shape[:1]:
+        raise ValueError("scores must be [B_local, F] and pattern_id [B_local]")
+    if pattern_id.numel() and int(pattern_id.abs().max()) >= 1 << 24:
+        raise ValueError("pattern_id does not fit a float32 record exactly")
+    rec = torch.cat([scores.float(), pattern_id.float().unsqueeze(1)], dim=1)
+    full = gather_rows(rec, total, group)
+    return full[:, :-1].contiguous(), full[:, -1].round().to(torch.int32)
+
+
+def global_mask_count(local_count: torch.Tensor, local_batch: int, group=None) -> Tuple[int, int]:
+    """(sum of masked positions, sum of batch rows) over the group: the operands of the batch-average
+    mask count of generation_utils.py:520.  `local_count` is a one-element integer tensor on the device the
+    backend communicates from."""
+    world, _ = _world(group)
+    if world == 1:
+        return int(local_count), local_batch
+    t = torch.stack([local_count.reshape(()).to(torch.int64),
+                     torch.tensor(local_batch, dtype=torch.int64, device=local_count.device)])
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t[0]), int(t[1])
+
+
+@torch.no_grad()
+def generate_sharded(model, inputs: torch.Tensor, generation_config=None, *, group=None, gather: bool = True,
+                     exact_ragged_k: bool = False, attention_mask: Optional[torch.Tensor] = None,
+                     **kwargs) -> torch.Tensor:
+    """``model.diffusion_generate`` over this rank's row block of `inputs` (same tensor on every rank),
+    then, if `gather`, an all_gather of the `[B_local, N]` sequences so every rank returns `[B, N]`.
+
+    RNG: each rank draws from its own device generator, so stochastic parity (temperature > 0) is defined per
+    shard: same seed + same rows => same result as an unsharded call on those rows alone.
+    `exact_ragged_k`: all-reduce the mask count every step (only matters when rows carry different numbers of
+    masks)."""
+    world, rank = _world(group)
+    total = inputs.shape[0]
+    lo, hi = shard_bounds(total, world, rank)
+    kwargs = dict(kwargs)
+    kwargs["return_dict_in_generate"] = False
+    if attention_mask is not None:
+        kwargs["attention_mask"] = attention_mask[lo:hi]
+    if exact_ragged_k and world > 1:
+        if total < world:
+            raise ValueError("exact_ragged_k needs at least one row per rank (every rank joins the per-step all-reduce)")
+        kwargs["_count_reduce"] = lambda cnt, b: global_mask_count(cnt, b, group)
+    if hi > lo:
+        local = model.diffusion_generate(inputs[lo:hi], generation_config=generation_config, **kwargs)
+    else:
+        n = kwargs.get("max_length") or (generation_config.max_length if generation_config else inputs.shape[1] + 1)
+        local = inputs.new_empty((0, n))
+    if not gather:
+        return local
+    return gather_rows(local, total, group)

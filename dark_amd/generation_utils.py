@@ -176,6 +176,8 @@ class DreamGenerationMixin:
         self._rand_fn = kwargs.pop("_rand_fn", None)  # parity tests: inject alg='origin' uniforms
         trace = kwargs.pop("_trace", None)        # parity tests: dict receiving per-step k / conf / x0
         self._state_hook = kwargs.pop("_state_hook", None)  # parity tests: teacher forcing, (step, x) -> x
+        # dispatch.generate_sharded(exact_ragged_k=True): (count tensor, B_local) -> (global masks, global rows)
+        self._count_reduce = kwargs.pop("_count_reduce", None)
 
         assert inputs is not None
         input_ids = inputs
@@ -287,7 +289,8 @@ class DreamGenerationMixin:
         st.mask_rows(x, mask_id)              # row_index / src_rows / count, then async count read-back
         st.forward_hidden(x, pos, key_mask)   # enqueued before the host waits for the count
         M = st.wait_count()
-        k = transfer_count(M, B, t, s, last)
+        Mg, Bg = (M, B) if getattr(self, '_count_reduce', None) is None else self._count_reduce(st.count[:1], B)
+        k = transfer_count(Mg, Bg, t, s, last)
         if trace is not None:
             trace.setdefault("k", []).append(k)
             trace.setdefault("M", []).append(M)
@@ -333,7 +336,8 @@ class DreamGenerationMixin:
             else:
                 confidence = torch.empty(0, device=x.device)
                 x0 = torch.empty(0, device=x.device, dtype=torch.long)
-            k = transfer_count(int(mask_index.sum()), B, t, s, last)
+            Mg, Bg = (M, B) if getattr(self, '_count_reduce', None) is None else self._count_reduce(mask_index.sum().reshape(1), B)
+            k = transfer_count(Mg, Bg, t, s, last)
             if trace is not None:
                 trace.setdefault("k", []).append(k)
                 trace.setdefault("confidence", []).append(confidence.clone())

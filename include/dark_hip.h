@@ -141,6 +141,14 @@ int dark_denoise_step(const dark_model_desc* m, int64_t* x, const int32_t* pos, 
                       int conf_mode, const float* noise, int k, void* workspace, size_t workspace_bytes,
                       void* stream);
 
+/* ---- measurement hook (no counterpart in the reference): bracket every launch of ONE GEMM flavour
+ * (epi as in dark_dbg_gemm; -1 = off) with HIP events on the launch stream.  dark_prof_read waits for
+ * the recorded events, returns their summed duration, the algorithmic FLOPs (2*M*N*K) of those launches
+ * and their number, and resets the counters.  Used by bench.py for the live roofline figure; event
+ * objects are created on first use while the hook is on (the only allocation in the library). */
+int dark_prof_select_gemm(int epi);
+int dark_prof_read(double* total_ms, double* total_flops, int* launches);
+
 /* ---- unit-test hooks (no counterpart in the reference): launch ONE kernel of the path so that
  * tests/test_hip_kernels.py can pin it against the oracle in isolation.
  *   epi: 0 = +bias (out in model dtype), 1 = residual add into fp32 out, 2 = SwiGLU over interleaved
