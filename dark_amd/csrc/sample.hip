@@ -2,14 +2,20 @@
 //
 // Replaces sample_tokens (generation_utils.py:58-90), top_p_logits (:37-48) and top_k_logits
 // (:50-55): a full descending sort, a cumsum, a scatter and ~8 elementwise passes over [M,V] in the
-// reference become one workgroup per masked row with the row resident in LDS.
+// reference become one workgroup per masked row with the row resident in LDS (HBM traffic: the row
+// and its noise row once each).
 //
 // Nucleus filter without a sort: the kept set of top_p_logits is the prefix of the descending order
-// up to and including the first element whose inclusive cumulative probability exceeds top_p.  That
-// element is found by a 3-level (11+11+10 bit) radix select over the order-preserving integer image
-// of the logits, where each histogram bin accumulates probability MASS in 2^-40 fixed point
-// (integer LDS atomics: order independent, hence deterministic).  Equal logits keep index order
-// (torch's CPU sort is stable).  top_k uses the same select with unit weights.
+// up to and including the first element whose inclusive cumulative probability exceeds top_p.  All
+// cumulative sums are integers (probability MASS in 2^-40 fixed point), so they are order independent
+// and deterministic.  The crossing element is found in two stages:
+//   1. one histogram pass over bins that are LINEAR in (row max - logit), 28/1023 wide (mass is 0 beyond 27.7),
+//      so the row spreads over the bins and the LDS atomics do not pile up on a few addresses; the bin
+//      map is monotone in the logit, hence bins are contiguous ranges of the descending order;
+//   2. the handful of elements of the crossing bin are gathered and resolved exactly (O(c^2/512) per thread).
+// If the crossing bin holds more than CAND_CAP elements (e.g. a flat row), an exact 4 x 8-bit radix select
+// over the order-preserving integer image of the logits takes over; top_k always uses that select with
+// unit weights.  Equal logits keep index order (torch's CPU sort is stable).
 //
 // Draw: x0 = argmax_i (p_i / psum) / q_i with q ~ Exp(1) supplied by the caller, which is the ATen
 // multinomial(1) that Categorical(probs).sample() runs; ties -> lowest index (torch argmax).
@@ -17,8 +23,11 @@
 
 namespace dark {
 
-constexpr int ST = 512;  // threads per row (8 waves)
-constexpr int NBIN = 2048;
+constexpr int ST = 512;         // threads per row (8 waves)
+constexpr int NLIN = 1024;      // linear bins of stage 1
+constexpr int NRAD = 256;       // radix bins of the fallback select
+constexpr int CAND_CAP = 1024;  // elements of the crossing bin resolved exactly
+constexpr float LIN_RANGE = 28.0f;
 #define DARK_FLT_LOWEST (-3.4028234663852886e38f)  // torch.finfo(torch.float32).min
 
 __device__ __forceinline__ uint32_t fkey(float f) {  // order-preserving float -> uint
@@ -32,14 +41,19 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
 __device__ __forceinline__ unsigned long long mass_fx(float l, float mx) {
   return (unsigned long long)(expf(l - mx) * 1099511627776.0f);  // 2^40
 }
+__device__ __forceinline__ int lin_bin(float l, float mx) {
+  const float d = (mx - l) * ((float)(NLIN - 1) / LIN_RANGE);  // monotone non-increasing in l
+  return d < (float)(NLIN - 1) ? (int)d : NLIN - 1;            // NaN / inf / huge -> last bin
+}
 
 struct Scratch {
   unsigned long long u64[8];
-  double f64[8];
+  double f64a[8], f64b[8];
   float f32a[8], f32b[8], f32c[8];
   int i32[8];
+  uint32_t u32[8];
   // select broadcast
-  int found, bin;
+  int found, bin, ncand;
   unsigned long long above;
 };
 
@@ -53,15 +67,37 @@ __device__ __forceinline__ float block_max(float v, Scratch* s, int tid) {
   for (int w = 1; w < ST / 64; ++w) r = fmaxf(r, s->f32a[w]);
   return r;
 }
+__device__ __forceinline__ uint32_t block_max_u32(uint32_t v, Scratch* s, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+  __syncthreads();
+  if ((tid & 63) == 0) s->u32[tid >> 6] = v;
+  __syncthreads();
+  uint32_t r = s->u32[0];
+#pragma unroll
+  for (int w = 1; w < ST / 64; ++w) r = max(r, s->u32[w]);
+  return r;
+}
 __device__ __forceinline__ double block_sum(double v, Scratch* s, int tid) {
   v = wave_sum(v);
   __syncthreads();
-  if ((tid & 63) == 0) s->f64[tid >> 6] = v;
+  if ((tid & 63) == 0) s->f64a[tid >> 6] = v;
   __syncthreads();
-  double r = s->f64[0];
+  double r = s->f64a[0];
 #pragma unroll
-  for (int w = 1; w < ST / 64; ++w) r += s->f64[w];
+  for (int w = 1; w < ST / 64; ++w) r += s->f64a[w];
   return r;
+}
+__device__ __forceinline__ void block_sum2(double& a, double& b, Scratch* s, int tid) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  __syncthreads();
+  if ((tid & 63) == 0) { s->f64a[tid >> 6] = a; s->f64b[tid >> 6] = b; }
+  __syncthreads();
+  a = s->f64a[0];
+  b = s->f64b[0];
+#pragma unroll
+  for (int w = 1; w < ST / 64; ++w) { a += s->f64a[w]; b += s->f64b[w]; }
 }
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, Scratch* s, int tid) {
 #pragma unroll
@@ -75,9 +111,44 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
   return r;
 }
 
-// Finds the first element, in descending key order, whose inclusive cumulative weight exceeds T.
-// weight = 2^-40 fixed-point softmax mass (MASS) or 1 (count).  On success returns true with
-// *tau = its key, *above = total weight of keys strictly greater, *n_tau = multiplicity of that key.
+// Wave 0 scans `nbin` weight bins in the order first = bin `start`, step `dir` (the descending-logit order)
+// for the first non-empty bin whose inclusive cumulative weight, starting from A, exceeds T.
+// Publishes s->found / s->bin / s->above (weight strictly before that bin).  nbin must be a multiple of 64.
+__device__ __forceinline__ void scan_crossing(const unsigned long long* hist, int nbin, int start, int dir,
+                                              unsigned long long A, unsigned long long T, Scratch* s, int tid) {
+  if (tid < 64) {
+    const int per = nbin >> 6;
+    const int first = start + dir * per * tid;  // lane L owns `per` consecutive bins of the scan order
+    unsigned long long tot = 0;
+    for (int q = 0; q < per; ++q) tot += hist[first + dir * q];
+    unsigned long long inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long t = __shfl_up(inc, o, 64);
+      if (tid >= o) inc += t;
+    }
+    unsigned long long run = A + inc - tot;  // weight strictly before this lane's bins
+    int hit = -1;
+    unsigned long long hit_above = 0;
+    for (int q = 0; q < per; ++q) {
+      const unsigned long long hq = hist[first + dir * q];
+      if (hit < 0 && hq != 0 && run + hq > T) { hit = first + dir * q; hit_above = run; }
+      run += hq;
+    }
+    const unsigned long long bal = __ballot(hit >= 0);
+    if (bal == 0) {
+      if (tid == 0) s->found = 0;
+    } else {
+      const int firstl = __ffsll((long long)bal) - 1;
+      if (tid == firstl) { s->found = 1; s->bin = hit; s->above = hit_above; }
+    }
+  }
+}
+
+// Exact radix select (4 levels of 8 bits) over the integer image of the logits: finds the first element, in
+// descending key order, whose inclusive cumulative weight exceeds T.  weight = 2^-40 fixed-point softmax
+// mass (MASS) or 1 (count).  On success returns true with *tau = its key, *above = total weight of keys
+// strictly greater, *n_tau = multiplicity of that key.
 template <bool MASS>
 __device__ bool select_crossing(const float* row, int V, float mx, unsigned long long T,
                                 unsigned long long* hist, unsigned int* cnth, Scratch* s, int tid,
@@ -85,61 +156,98 @@ __device__ bool select_crossing(const float* row, int V, float mx, unsigned long
   uint32_t prefix = 0;
   int pbits = 0;
   unsigned long long A = 0;
-  int last_bin = 0;
-  for (int level = 0; level < 3; ++level) {
-    const int bits = level < 2 ? 11 : 10;
-    const int shift = 32 - pbits - bits;
-    for (int i = tid; i < NBIN; i += ST) { hist[i] = 0; cnth[i] = 0; }
+  for (int level = 0; level < 4; ++level) {
+    const int shift = 24 - 8 * level;
+    for (int i = tid; i < NRAD; i += ST) { hist[i] = 0; cnth[i] = 0; }
     __syncthreads();
     for (int i = tid; i < V; i += ST) {
       const float l = row[i];
       const uint32_t k = fkey(l);
       if (pbits == 0 || (k >> (32 - pbits)) == prefix) {
-        const int dg = (k >> shift) & ((1u << bits) - 1u);
+        const int dg = (k >> shift) & 0xffu;
         atomicAdd(&hist[dg], MASS ? mass_fx(l, mx) : 1ull);
         atomicAdd(&cnth[dg], 1u);
       }
     }
     __syncthreads();
-    if (tid < 64) {  // wave 0: lane L owns bins [NBIN-1-32L-31, NBIN-1-32L], scanned downwards
-      const int top = NBIN - 1 - 32 * tid;
-      unsigned long long tot = 0;
-      for (int q = 0; q < 32; ++q) tot += hist[top - q];
-      unsigned long long inc = tot;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long t = __shfl_up(inc, o, 64);
-        if (tid >= o) inc += t;
-      }
-      unsigned long long run = A + inc - tot;  // weight strictly above this lane's bins
-      int hit = -1;
-      unsigned long long hit_above = 0;
-      for (int q = 0; q < 32; ++q) {
-        const unsigned long long hq = hist[top - q];
-        if (hit < 0 && hq != 0 && run + hq > T) { hit = top - q; hit_above = run; }
-        run += hq;
-      }
-      const unsigned long long bal = __ballot(hit >= 0);
-      if (bal == 0) {
-        if (tid == 0) s->found = 0;
-      } else {
-        const int first = __ffsll((long long)bal) - 1;
-        if (tid == first) { s->found = 1; s->bin = hit; s->above = hit_above; }
-      }
-    }
+    scan_crossing(hist, NRAD, NRAD - 1, -1, A, T, s, tid);
     __syncthreads();
     if (!s->found) return false;
-    last_bin = s->bin;
+    const int b = s->bin;
     A = s->above;
-    prefix = (prefix << bits) | (uint32_t)last_bin;
-    pbits += bits;
-    // hist/cnth are re-zeroed at the top of the next level after this barrier-protected read
-    if (level == 2) *n_tau = (int)cnth[last_bin];
-    __syncthreads();
+    prefix = (prefix << 8) | (uint32_t)b;
+    pbits += 8;
+    if (level == 3) *n_tau = (int)cnth[b];
+    __syncthreads();  // hist/cnth are re-zeroed at the top of the next level
   }
   *tau = prefix;
   *above = A;
   return true;
+}
+
+// Stage 1 + 2 of the nucleus search (see the header).  Returns 1 = found, 0 = no crossing (nothing to
+// filter), -1 = the crossing bin overflows CAND_CAP (caller falls back to the radix select).
+__device__ int nucleus_crossing(const float* row, int V, float mx, unsigned long long* Zout, float top_p,
+                                unsigned long long* hist, uint32_t* cand, Scratch* s, int tid, uint32_t* tau,
+                                unsigned long long* above, int* n_tau, unsigned long long* Tout) {
+  for (int i = tid; i < NLIN; i += ST) hist[i] = 0;
+  if (tid == 0) s->ncand = 0;
+  __syncthreads();
+  unsigned long long zl = 0;
+  for (int i = tid; i < V; i += ST) {
+    const float l = row[i];
+    const unsigned long long fx = mass_fx(l, mx);
+    zl += fx;
+    if (fx) atomicAdd(&hist[lin_bin(l, mx)], fx);
+  }
+  const unsigned long long Z = block_sum_u64(zl, s, tid);  // (its barriers also publish the histogram)
+  const unsigned long long T = (unsigned long long)((double)top_p * (double)Z);  // floor
+  *Zout = Z;
+  *Tout = T;
+  scan_crossing(hist, NLIN, 0, +1, 0ull, T, s, tid);
+  __syncthreads();
+  if (!s->found) return 0;
+  const int b = s->bin;
+  const unsigned long long A = s->above;
+  for (int i = tid; i < V; i += ST) {
+    const float l = row[i];
+    if (lin_bin(l, mx) == b) {
+      const int slot = atomicAdd(&s->ncand, 1);
+      if (slot < CAND_CAP) cand[slot] = fkey(l);
+    }
+  }
+  __syncthreads();
+  const int c = s->ncand;
+  if (c > CAND_CAP) return -1;
+  // exact resolution: tau = the largest candidate key whose inclusive cumulative mass exceeds T
+  uint32_t best = 0;
+  for (int j = tid; j < c; j += ST) {
+    const uint32_t kj = cand[j];
+    unsigned long long S = A;
+    for (int i = 0; i < c; ++i) {
+      const uint32_t ki = cand[i];
+      if (ki >= kj) S += mass_fx(fkey_inv(ki), mx);
+    }
+    if (S > T) best = max(best, kj);
+  }
+  best = block_max_u32(best, s, tid);
+  if (best == 0) return 0;  // cannot happen when the bin scan found a crossing; be safe
+  if (tid == 0) {
+    unsigned long long S = A;
+    int n = 0;
+    for (int i = 0; i < c; ++i) {
+      const uint32_t ki = cand[i];
+      if (ki > best) S += mass_fx(fkey_inv(ki), mx);
+      n += ki == best;
+    }
+    s->above = S;
+    s->bin = n;
+  }
+  __syncthreads();
+  *tau = best;
+  *above = s->above;
+  *n_tau = s->bin;
+  return 1;
 }
 
 __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ logits, int64_t ldl, int V,
@@ -149,33 +257,48 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int vp = (V + 3) & ~3;
   float* row = (float*)smem;
-  unsigned long long* hist = (unsigned long long*)(smem + (size_t)vp * 4);
-  unsigned int* cnth = (unsigned int*)(hist + NBIN);
-  Scratch* s = (Scratch*)(cnth + NBIN);
+  unsigned long long* hist = (unsigned long long*)(smem + (size_t)vp * 4);  // NLIN u64; radix hist/cnt alias it
+  unsigned int* cnth = (unsigned int*)(hist + NRAD);
+  uint32_t* cand = (uint32_t*)(hist + NLIN);
+  Scratch* s = (Scratch*)(cand + CAND_CAP);
   const int tid = threadIdx.x;
   const int m = blockIdx.x;
   const float* lr = logits + (int64_t)m * ldl;
 
   // 1. temperature (generation_utils.py:60-61) and row max
   float mx = -INFINITY;
-  for (int i = tid; i < V; i += ST) {
-    float l = lr[i];
-    if (temperature > 0.f) l = l / temperature;
-    row[i] = l;
-    mx = fmaxf(mx, l);
+  if ((ldl & 3) == 0 && ((uintptr_t)logits & 15) == 0) {
+    const int v4 = V >> 2;
+    for (int i = tid; i < v4; i += ST) {
+      float4 l = *(const float4*)(lr + 4 * i);
+      if (temperature > 0.f) { l.x = l.x / temperature; l.y = l.y / temperature; l.z = l.z / temperature; l.w = l.w / temperature; }
+      *(float4*)(row + 4 * i) = l;
+      mx = fmaxf(fmaxf(mx, fmaxf(l.x, l.y)), fmaxf(l.z, l.w));
+    }
+    for (int i = 4 * v4 + tid; i < V; i += ST) {
+      float l = lr[i];
+      if (temperature > 0.f) l = l / temperature;
+      row[i] = l;
+      mx = fmaxf(mx, l);
+    }
+  } else {
+    for (int i = tid; i < V; i += ST) {
+      float l = lr[i];
+      if (temperature > 0.f) l = l / temperature;
+      row[i] = l;
+      mx = fmaxf(mx, l);
+    }
   }
   mx = block_max(mx, s, tid);
 
   // 2. nucleus filter (generation_utils.py:37-48)
   if (top_p > 0.f && top_p < 1.f) {
-    unsigned long long zl = 0;
-    for (int i = tid; i < V; i += ST) zl += mass_fx(row[i], mx);
-    const unsigned long long Z = block_sum_u64(zl, s, tid);
-    const unsigned long long T = (unsigned long long)((double)top_p * (double)Z);  // floor
-    uint32_t tau;
-    unsigned long long above;
-    int n_tau;
-    if (select_crossing<true>(row, V, mx, T, hist, cnth, s, tid, &tau, &above, &n_tau)) {
+    uint32_t tau = 0;
+    unsigned long long above = 0, Z = 0, T = 0;
+    int n_tau = 0;
+    int rc = nucleus_crossing(row, V, mx, &Z, top_p, hist, cand, s, tid, &tau, &above, &n_tau, &T);
+    if (rc < 0) rc = select_crossing<true>(row, V, mx, T, hist, cnth, s, tid, &tau, &above, &n_tau) ? 1 : 0;
+    if (rc > 0) {
       const unsigned long long fx = mass_fx(fkey_inv(tau), mx);
       unsigned long long t_keep = fx ? (T - above) / fx + 1ull : (unsigned long long)n_tau;
       if (t_keep >= (unsigned long long)n_tau) {
@@ -222,9 +345,13 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
     __syncthreads();
   }
 
-  // 4. softmax (generation_utils.py:66): p_i = exp(l_i - max) / Z
+  // 4. softmax (generation_utils.py:66): p_i = exp(l_i - max) / Z; the row now holds exp(l_i - max)
   double zs = 0.0;
-  for (int i = tid; i < V; i += ST) zs += (double)expf(row[i] - mx);
+  for (int i = tid; i < V; i += ST) {
+    const float e = expf(row[i] - mx);
+    row[i] = e;
+    zs += (double)e;
+  }
   const float Zf = (float)block_sum(zs, s, tid);
 
   double ps = 0.0, ent = 0.0;
@@ -232,14 +359,15 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   float bestp = -INFINITY;
   int besti = 0x7fffffff;
   for (int i = tid; i < V; i += ST) {
-    const float p = expf(row[i] - mx) / Zf;
+    const float p = row[i] / Zf;
     ps += (double)p;
-    ent += (double)(p * logf(p + 1e-10f));
+    if (conf_mode == DARK_CONF_NEG_ENTROPY) ent += (double)(p * logf(p + 1e-10f));
     if (p > t1) { t2 = t1; t1 = p; } else if (p > t2) { t2 = p; }
     if (p > bestp) { bestp = p; besti = i; }
   }
-  const float psum = (float)block_sum(ps, s, tid);
-  const float entropy = (float)block_sum(ent, s, tid);
+  block_sum2(ps, ent, s, tid);
+  const float psum = (float)ps;
+  const float entropy = (float)ent;
 
   // 5. draw (generation_utils.py:68-75)
   if (temperature > 0.f) {
@@ -247,7 +375,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
     bestp = -INFINITY;
     besti = 0x7fffffff;
     for (int i = tid; i < V; i += ST) {
-      const float p = expf(row[i] - mx) / Zf;
+      const float p = row[i] / Zf;
       const float r = (p / psum) / qr[i];
       if (r > bestp) { bestp = r; besti = i; }
     }
@@ -282,7 +410,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
     float c;
     if (conf_mode == DARK_CONF_NEG_ENTROPY) c = entropy;
     else if (conf_mode == DARK_CONF_MARGIN) c = a1 - a2;
-    else c = expf(row[bi] - mx) / Zf;
+    else c = row[bi] / Zf;
     conf[m] = c;
     x0[m] = (int64_t)bi;
   }
@@ -297,7 +425,8 @@ int launch_sample(const float* logits, int64_t ldl, int M, int V, float temperat
   DARK_CHECK_ARG(conf_mode >= 0 && conf_mode <= 2, "sample_rows: bad conf_mode %d", conf_mode);
   DARK_CHECK_ARG(!(temperature > 0.f) || (noise && ldn >= V), "sample_rows: temperature > 0 needs noise [M,V]");
   DARK_CHECK_ARG(temperature >= 0.f, "sample_rows: negative temperature");
-  const int smem = ((V + 3) & ~3) * 4 + NBIN * 8 + NBIN * 4 + (int)sizeof(Scratch);
+  static_assert(NRAD * 12 <= NLIN * 8, "the radix histograms alias the linear histogram");
+  const int smem = ((V + 3) & ~3) * 4 + NLIN * 8 + CAND_CAP * 4 + (int)sizeof(Scratch);
   static int attr_smem = 0;
   if (smem > attr_smem) {
     DARK_CHECK_HIP(hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
