@@ -38,8 +38,26 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
   const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
   return __uint_as_float(u);
 }
+// exp(x) for x <= 0 on the hardware exp2 (v_exp_f32, 1 ulp): the argument x*log2(e) is carried as a rounded
+// product plus its exact residual (fma) and the low word of log2(e), so the result is good to ~2 ulp over the
+// whole range instead of the |x| * 6e-8 relative error of the plain exp2f(x * log2e).  Results below 2^-126
+// flush to zero (they are < 1e-37 relative to the row maximum).
+__device__ __forceinline__ float exp_neg(float x) {
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f;
+  const float t = x * L2E_HI;
+  float r = fmaf(x, L2E_HI, -t);
+  r = fmaf(x, L2E_LO, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.693147180559945309f, e);
+}
+// ln(x) for 1e-10 <= x <= ~1 on v_log_f32 (1 ulp in log2)
+__device__ __forceinline__ float log_pos(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+
+constexpr float MASS_RANGE = 27.8f;  // exp(-27.8) * 2^40 < 1: fixed-point mass is 0 beyond
 __device__ __forceinline__ unsigned long long mass_fx(float l, float mx) {
-  return (unsigned long long)(expf(l - mx) * 1099511627776.0f);  // 2^40
+  const float d = l - mx;
+  if (!(d > -MASS_RANGE)) return 0ull;
+  return (unsigned long long)(exp_neg(d) * 1099511627776.0f);  // 2^40
 }
 __device__ __forceinline__ int lin_bin(float l, float mx) {
   const float d = (mx - l) * ((float)(NLIN - 1) / LIN_RANGE);  // monotone non-increasing in l
@@ -346,11 +364,19 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   }
 
   // 4. softmax (generation_utils.py:66): p_i = exp(l_i - max) / Z; the row now holds exp(l_i - max)
+  // Filtered entries (finfo.min) are exactly 0 after the softmax and contribute exactly 0 to every sum
+  // below, so the passes from here on only do work for the kept set: the branches are
+  // wave-uniform-false for almost every wave of a filtered row, and the noise row is only touched at the
+  // kept positions.
   double zs = 0.0;
   for (int i = tid; i < V; i += ST) {
-    const float e = expf(row[i] - mx);
+    const float d = row[i] - mx;
+    float e = 0.f;
+    if (d > -104.f) {  // exp(-104) < 2^-149: exactly 0 in fp32 below
+      e = exp_neg(d);
+      zs += (double)e;
+    }
     row[i] = e;
-    zs += (double)e;
   }
   const float Zf = (float)block_sum(zs, s, tid);
 
@@ -359,25 +385,31 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   float bestp = -INFINITY;
   int besti = 0x7fffffff;
   for (int i = tid; i < V; i += ST) {
-    const float p = row[i] / Zf;
-    ps += (double)p;
-    if (conf_mode == DARK_CONF_NEG_ENTROPY) ent += (double)(p * logf(p + 1e-10f));
-    if (p > t1) { t2 = t1; t1 = p; } else if (p > t2) { t2 = p; }
-    if (p > bestp) { bestp = p; besti = i; }
+    const float e = row[i];
+    if (e > 0.f) {
+      const float p = e / Zf;
+      row[i] = p;
+      ps += (double)p;
+      if (conf_mode == DARK_CONF_NEG_ENTROPY) ent += (double)(p * log_pos(p + 1e-10f));
+      if (p > t1) { t2 = t1; t1 = p; } else if (p > t2) { t2 = p; }
+      if (p > bestp) { bestp = p; besti = i; }
+    }
   }
   block_sum2(ps, ent, s, tid);
   const float psum = (float)ps;
   const float entropy = (float)ent;
 
-  // 5. draw (generation_utils.py:68-75)
+  // 5. draw (generation_utils.py:68-75): argmax of (p / psum) / q; entries with p == 0 give 0 and never win
   if (temperature > 0.f) {
     const float* qr = noise + (int64_t)m * ldn;
     bestp = -INFINITY;
     besti = 0x7fffffff;
     for (int i = tid; i < V; i += ST) {
-      const float p = row[i] / Zf;
-      const float r = (p / psum) / qr[i];
-      if (r > bestp) { bestp = r; besti = i; }
+      const float p = row[i];
+      if (p > 0.f) {
+        const float r = (p / psum) / qr[i];
+        if (r > bestp) { bestp = r; besti = i; }
+      }
     }
   }
   // block arg-max, ties -> lowest index; merge the (top1, top2) pairs alongside
@@ -407,10 +439,11 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
       a1 = n1; a2 = n2;
     }
     if (bi < 0 || bi >= V) bi = 0;  // all-NaN row: keep the index in range
+    if (a2 < 0.f) a2 = 0.f;         // fewer than two non-zero probabilities: the runner-up is a zero
     float c;
     if (conf_mode == DARK_CONF_NEG_ENTROPY) c = entropy;
     else if (conf_mode == DARK_CONF_MARGIN) c = a1 - a2;
-    else c = row[bi] / Zf;
+    else c = row[bi];
     conf[m] = c;
     x0[m] = (int64_t)bi;
   }
