@@ -19,6 +19,10 @@ namespace dark {
 constexpr int BM = 128, BN = 128;
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g)); }
+// bf16 epilogues: hardware exp2 / rcp (1 ulp each), far below the bf16 rounding of the result
+__device__ __forceinline__ float silu_fast(float g) {
+  return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896340736f));
+}
 
 // acc[mi][ni][r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 inside a 32x32 tile
 template <int EPI, typename T>
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
     if constexpr (EPI == EPI_SWIGLU) {
       float v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = silu_f(acc[0][mi][r]) * acc[1][mi][r];
+      for (int r = 0; r < 16; ++r) v[r] = silu_fast(acc[0][mi][r]) * acc[1][mi][r];
       store_tile_bf16(v, (bf16_t*)out + mrow * ldo, tn * 64 + wn * 32, N >> 1, fh, row_ok, vec_ok);
     } else {
 #pragma unroll
@@ -245,6 +249,174 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
                 else orow[c + e] = acc[ni][mi][4 * g + e];
               }
             }
+          }
+        }
+      }
+    }
+  }
+}
+
+// Two horizontally adjacent 16x16 tiles of final values of this lane (row m; tile t holds columns
+// cb + 16t + 4q + e, q = lane >> 4) stored as bf16 in 16-B pieces: one permlane16_swap per dword moves the
+// odd 16-lane rows' first-tile data to their even neighbours and the even rows' second-tile data to the odd
+// ones, so even rows own columns 4q..4q+7 of the first tile and odd rows 4(q-1)..4(q-1)+7 of the second.
+__device__ __forceinline__ void store_pair_bf16(const float (&v0)[4], const float (&v1)[4], bf16_t* __restrict__ orow,
+                                                int cb, int ncols, int q, bool vec_ok) {
+  const uint32_t a_lo = pack_bf16x2(v0[0], v0[1]), a_hi = pack_bf16x2(v0[2], v0[3]);
+  const uint32_t b_lo = pack_bf16x2(v1[0], v1[1]), b_hi = pack_bf16x2(v1[2], v1[3]);
+  if (vec_ok) {
+    const auto sx = __builtin_amdgcn_permlane16_swap(a_lo, b_lo, false, false);
+    const auto sy = __builtin_amdgcn_permlane16_swap(a_hi, b_hi, false, false);
+    const int c = cb + ((q & 1) ? 16 + 4 * (q - 1) : 4 * q);
+    if (c + 8 <= ncols) *(uint4*)(orow + c) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+  } else {
+    const uint32_t w[4] = {a_lo, a_hi, b_lo, b_hi};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = cb + 16 * t + 4 * q + e;
+        if (c < ncols) ((uint16_t*)orow)[c] = (uint16_t)(w[2 * t + (e >> 1)] >> (16 * (e & 1)));
+      }
+  }
+}
+
+// ------------------------------------------------------------------ bf16, 16x16x32 MFMA shape
+// Same tile, staging and pipeline as gemm_bf16_kernel; the wave's 64x64 block is 4x4 tiles of
+// v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on this shape under sustained load).
+// Accumulator map (operands swapped): lane owns row m = lane & 15 and columns 4*(lane>>4) + e of a tile.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __restrict__ A,
+                                                             const bf16_t* __restrict__ W,
+                                                             const float* __restrict__ bias,
+                                                             void* __restrict__ out, int M, int N, int K,
+                                                             int64_t ldo, int tilesM, int tilesN, int nwg,
+                                                             int vec_ok) {
+  constexpr int BK = 64;
+  constexpr int TILE = BM * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int GM = 8;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int per_group = GM * tilesN;
+  const int group = wg / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(GM, tilesM - first_m);
+  const int rem = wg - group * per_group;
+  const int tn = rem / gsz, tm = first_m + (rem - tn * gsz);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const bf16_t* ga[4];
+  const bf16_t* gw[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = wave * 32 + q * 8 + (lane >> 3);
+    const int lch = (lane & 7) ^ ((row >> 1) & 7);
+    const int ar = min(m0 + row, M - 1);
+    const int wr = min(n0 + row, N - 1);
+    ga[q] = A + (int64_t)ar * K + lch * 8;
+    gw[q] = W + (int64_t)wr * K + lch * 8;
+  }
+  char* const lstage = smem + wave * 4096;
+  auto stage = [&](int buf, int kt) {
+    char* a = lstage + buf * 2 * TILE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      DARK_GLDS16(ga[q] + kt * BK, a + q * 1024);
+      DARK_GLDS16(gw[q] + kt * BK, a + TILE + q * 1024);
+    }
+  };
+
+  f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int KT = K / BK;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int fsw = (frow >> 1) & 7;
+  auto compute = [&](int buf) {
+    const char* as = smem + buf * 2 * TILE + (wm * 64 + frow) * 128;
+    const char* ws = smem + buf * 2 * TILE + TILE + (wn * 64 + frow) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = ((4 * ks + fq) ^ fsw) << 4;
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *(const bf16x8*)(as + i * 16 * 128 + ch);
+        wf[i] = *(const bf16x8*)(ws + i * 16 * 128 + ch);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+    }
+  };
+
+  stage(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) stage((kt + 1) & 1, kt + 1);
+    compute(kt & 1);
+  }
+
+  // rows beyond M are computed on clamped operands and dropped here; the permlane swaps run in every lane
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + frow;
+    const bool row_ok = m < M;
+    const int64_t mrow = row_ok ? m : 0;
+    if constexpr (EPI == EPI_SWIGLU) {
+      float v[2][4];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[ni][e] = silu_fast(acc[ni][mi][e]) * acc[ni + 2][mi][e];
+      store_pair_bf16(v[0], v[1], (bf16_t*)out + mrow * ldo, tn * 64 + wn * 32, row_ok ? (N >> 1) : 0, fq, vec_ok);
+    } else if constexpr (EPI == EPI_BIAS) {
+#pragma unroll
+      for (int np = 0; np < 2; ++np) {
+        float v[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int ni = 2 * np + t;
+          const int c = n0 + wn * 64 + ni * 16 + 4 * fq;
+          if (vec_ok && c + 4 <= N) {
+            const float4 b4 = *(const float4*)(bias + c);
+            v[t][0] = acc[ni][mi][0] + b4.x; v[t][1] = acc[ni][mi][1] + b4.y;
+            v[t][2] = acc[ni][mi][2] + b4.z; v[t][3] = acc[ni][mi][3] + b4.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[t][e] = acc[ni][mi][e] + (c + e < N ? bias[c + e] : 0.f);
+          }
+        }
+        store_pair_bf16(v[0], v[1], (bf16_t*)out + mrow * ldo, n0 + wn * 64 + np * 32, row_ok ? N : 0, fq, vec_ok);
+      }
+    } else {
+      if (!row_ok) continue;
+      float* orow = (float*)out + mrow * ldo;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int c = n0 + wn * 64 + ni * 16 + 4 * fq;
+        if (vec_ok && c + 4 <= N) {
+          float4 o = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+          if constexpr (EPI == EPI_RESID) {
+            const float4 p = *(const float4*)(orow + c);
+            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+          }
+          *(float4*)(orow + c) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (c + e >= N) continue;
+            if constexpr (EPI == EPI_RESID) orow[c + e] += acc[ni][mi][e];
+            else orow[c + e] = acc[ni][mi][e];
           }
         }
       }
@@ -342,19 +514,26 @@ static int launch_epi(int dtype, const void* A, const void* W, const float* bias
   const int nwg = tilesM * tilesN;
   if (dtype == DARK_BF16) {
     constexpr int smem = 4 * BM * 64 * 2;  // 64 KiB
-    static bool attr_done = false;
-    if (!attr_done) {
-      DARK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-      attr_done = true;
-    }
     // 16-B row pieces need 16-B aligned rows: bf16 outputs 8 elements, fp32 outputs 4
     const int per16 = (EPI == EPI_BIAS || EPI == EPI_SWIGLU) ? 8 : 4;
     const int ncols = EPI == EPI_SWIGLU ? N / 2 : N;
     const int vec_ok = (ldo % per16 == 0) && (ncols % per16 == 0) &&
                        ((uintptr_t)out % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nwg), dim3(256), smem, st, (const bf16_t*)A,
-                       (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, nwg, vec_ok);
+    // MFMA shape per flavour, by sustained measurement on MI355X (tools/gemm_check.py --iters 2000):
+    // 16x16x32 wins on the residual, SwiGLU and fp32-out flavours, 32x32x16 on the bias flavour.
+    constexpr bool k16 = EPI != EPI_BIAS;
+    const void* fn = k16 ? (const void*)gemm_bf16_kernel16<EPI> : (const void*)gemm_bf16_kernel<EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+      DARK_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      attr_done = true;
+    }
+    if constexpr (k16)
+      hipLaunchKernelGGL(gemm_bf16_kernel16<EPI>, dim3(nwg), dim3(256), smem, st, (const bf16_t*)A,
+                         (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, nwg, vec_ok);
+    else
+      hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nwg), dim3(256), smem, st, (const bf16_t*)A,
+                         (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, nwg, vec_ok);
   } else {
     hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nwg), dim3(256), 0, st, (const float*)A,
                        (const float*)W, bias, out, M, N, K, ldo, tilesN, nwg);
@@ -422,6 +601,7 @@ static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, co
   DARK_CHECK_ARG(dtype == DARK_F32 || dtype == DARK_BF16, "gemm: bad dtype %d", dtype);
   DARK_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   DARK_CHECK_ARG(K % 64 == 0, "gemm: K=%d must be a multiple of 64", K);
+  DARK_CHECK_ARG(M < (1 << 24) && N < (1 << 24), "gemm: M=%d N=%d too large", M, N);
   DARK_CHECK_ARG(A && W && out, "gemm: null operand");
   switch (epi) {
     case EPI_BIAS:
