@@ -91,16 +91,16 @@ def main():
     gc = DreamGenerationConfig(mask_token_id=synth.MASK, pad_token_id=synth.END, bos_token_id=synth.BOS,
                                eos_token_id=synth.END, sep_token_id=synth.SEP, max_length=46)
     gen_kw = dict(steps=args.denoise_steps, temperature=0.1, alg="entropy", alg_temp=0, top_p=0.9,
-                  number_transfer_tokens=1)
+                  number_transfer_tokens=1, skip_noop_steps=False)  # headline: every step runs its forward
     torch.manual_seed(2 + rank)
 
     import warnings
     warnings.filterwarnings("ignore", message="Padding was detected")
 
-    def one_step():
+    def one_step(**over):
         seqs = []
         for ids in (ids_abd, ids_ded):
-            seqs.append(model.diffusion_generate(ids, generation_config=gc, **gen_kw))
+            seqs.append(model.diffusion_generate(ids, generation_config=gc, **dict(gen_kw, **over)))
         out = torch.cat(seqs, 0)
         if world > 1:  # per-batch result gather (replaces all_gather_object of mdm_unify.py:436-438)
             out = dispatch.gather_rows(out, out.shape[0] * world)
@@ -127,10 +127,22 @@ def main():
     lib.dark_prof_select_gemm(-1)
     assert out.shape == (args.batch * world, 46) and int((out[:, 0] != synth.BOS).sum()) == 0
 
+    # secondary figure: the library default (skip_noop_steps=True) reuses the hidden states of an unchanged x on
+    # the steps whose transfer count is 0 (22 of 32 for the abduction half); same tokens, same RNG stream
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(skip_noop_steps=True)
+    fence()
+    dt_skip = time.perf_counter() - t1
+
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
+        t = torch.tensor([dt_skip], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_skip = float(t[0])
     seq_per_s = args.batch * world * args.steps / dt
 
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
@@ -146,8 +158,9 @@ def main():
                                "(10L d768 ff3072 H8, V=15080, N=46)",
                    "batch_per_gpu": args.batch, "denoise_steps": args.denoise_steps, "temperature": 0.1,
                    "top_p": 0.9, "alg": "entropy", "parallelism": f"dp{world}", "weights": "random-init"},
+        "value_skip_noop_steps": round(args.batch * world * args.steps / dt_skip, 2),
         "forward_mfma_frac": round(alg_flops * args.steps * world / dt / 1e12 / (peak * world), 4),
-        "roofline": {"bound": "mfma", "kernel": f"gemm_{args.dtype}_kernel<EPI_SWIGLU> (gate/up projection, "
+        "roofline": {"bound": "mfma", "kernel": f"gemm_{args.dtype}_kernel16<EPI_SWIGLU> (gate/up projection + SiLU*up, "
                                                 "M=B*N/2 rows per call, N=6144, K=768)",
                      "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": None, "launches": n.value,

@@ -137,6 +137,7 @@ class HipState:
         self.logits = None
         self.conf = torch.empty(rows, dtype=torch.float32, device=dev)
         self.x0 = torch.empty(rows, dtype=torch.int64, device=dev)
+        self.hidden_valid = False  # hidden / row_index / count describe the caller's current x
 
     def _s(self) -> int:
         return _hip.stream_ptr(self.pk.device)
@@ -377,6 +378,7 @@ class DreamModel_length(DreamGenerationMixin, nn.Module):
         if position_ids is not None:
             pos = position_ids.to(self.device).expand(B, N).to(torch.int32).contiguous()
         st = self._hip_state(B, N)
+        st.hidden_valid = False
         st.forward_hidden(x, pos, key_mask)
         logits = st.head_all_rows().view(B, N, self.config.vocab_size)
         if num_logits_to_keep:

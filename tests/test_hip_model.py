@@ -283,3 +283,22 @@ def test_save_and_from_pretrained_roundtrip(mini, tmp_path, goldens):
     assert m2.generation_config.mask_token_id == synth.MASK and m2.generation_config.max_length == 46
     ids = torch.from_numpy(goldens["fwd_ids"]).to(DEV)
     assert torch.equal(m2(ids).logits, mini(ids).logits)
+
+
+def test_skip_noop_steps_is_invisible(golden_meta):
+    """skip_noop_steps (default on) must not change tokens, history or the torch RNG stream: with 11 masks and
+    32 steps 22 steps commit nothing; their forward is reused, their noise draw is kept."""
+    kw = dict(golden_meta["real"], num_hidden_layers=2)
+    m = _model(kw, False)
+    ids = synth.make_inputs(16, "abd", seed=7).to(DEV)
+    res = []
+    for skip in (False, True):
+        torch.manual_seed(123)
+        out = m.diffusion_generate(inputs=ids, generation_config=_gc(45), return_dict_in_generate=True,
+                                   output_history=True, steps=32, temperature=0.5, alg="entropy", alg_temp=0,
+                                   top_p=0.9, skip_noop_steps=skip)
+        res.append((torch.stack(out.history).cpu(), torch.rand(4, device=DEV).cpu()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1]), "the device generator must end in the same state"
+    changed = (res[0][0][1:] != res[0][0][:-1]).any(-1).any(-1)
+    assert int(changed.sum()) <= 10  # only the 10 committing steps change x
