@@ -9,6 +9,7 @@
 //         (chunk ^= row & 7) so the ds_read_b128 fragment reads spread over the bank row.
 //   fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, k ascending), BK = 16, LDS rows padded to 17.
 // Double-buffered LDS, global loads of tile t+1 issued before the MFMAs of tile t (register staging).
+
 #include <utility>
 #include <vector>
 
@@ -285,7 +286,9 @@ __device__ __forceinline__ void store_pair_bf16(const float (&v0)[4], const floa
 // Same tile, staging and pipeline as gemm_bf16_kernel; the wave's 64x64 block is 4x4 tiles of
 // v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on this shape under sustained load).
 // Accumulator map (operands swapped): lane owns row m = lane & 15 and columns 4*(lane>>4) + e of a tile.
-template <int EPI>
+// BNt = 128, or 192 for the N = 768 GEMMs: 184 x 4 tiles fill 512 workgroup slots 2.9 times instead of 4.3
+// (96 % instead of 86 % tile quantisation at M = 23552) and cut the fragment reads per MFMA from 0.5 to 0.42.
+template <int EPI, int BNt>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __restrict__ A,
                                                              const bf16_t* __restrict__ W,
                                                              const float* __restrict__ bias,
@@ -293,12 +296,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
                                                              int64_t ldo, int tilesM, int tilesN, int nwg,
                                                              int vec_ok) {
   constexpr int BK = 64;
-  constexpr int TILE = BM * BK * 2;
+  constexpr int TILE = BM * BK * 2;              // activation tile bytes
+  constexpr int WTILE = BNt * BK * 2;            // weight tile bytes
+  constexpr int STAGE = TILE + WTILE;
+  constexpr int WN = BNt / 2;                    // columns per wave
+  constexpr int TNW = WN / 16;                   // 16-column MFMA tiles per wave
+  constexpr int WP = BNt / 32;                   // 8-row weight pieces staged per wave
+  constexpr int GM = BNt == 128 ? 8 : 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  constexpr int GM = 8;
   const int wg = xcd_remap(blockIdx.x, nwg);
   const int per_group = GM * tilesN;
   const int group = wg / per_group;
@@ -306,32 +314,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
   const int gsz = min(GM, tilesM - first_m);
   const int rem = wg - group * per_group;
   const int tn = rem / gsz, tm = first_m + (rem - tn * gsz);
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM, n0 = tn * BNt;
 
   const bf16_t* ga[4];
-  const bf16_t* gw[4];
+  const bf16_t* gw[WP];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = wave * 32 + q * 8 + (lane >> 3);
     const int lch = (lane & 7) ^ ((row >> 1) & 7);
-    const int ar = min(m0 + row, M - 1);
-    const int wr = min(n0 + row, N - 1);
-    ga[q] = A + (int64_t)ar * K + lch * 8;
-    gw[q] = W + (int64_t)wr * K + lch * 8;
+    ga[q] = A + (int64_t)min(m0 + row, M - 1) * K + lch * 8;
   }
-  char* const lstage = smem + wave * 4096;
-  auto stage = [&](int buf, int kt) {
-    char* a = lstage + buf * 2 * TILE;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      DARK_GLDS16(ga[q] + kt * BK, a + q * 1024);
-      DARK_GLDS16(gw[q] + kt * BK, a + TILE + q * 1024);
-    }
+  for (int q = 0; q < WP; ++q) {
+    const int row = wave * (WP * 8) + q * 8 + (lane >> 3);
+    const int lch = (lane & 7) ^ ((row >> 1) & 7);
+    gw[q] = W + (int64_t)min(n0 + row, N - 1) * K + lch * 8;  // rows >= N only feed columns never stored
+  }
+  auto stage = [&](int buf, int kt) {
+    char* a = smem + buf * STAGE + wave * 4096;
+    char* w = smem + buf * STAGE + TILE + wave * (WP * 1024);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) DARK_GLDS16(ga[q] + kt * BK, a + q * 1024);
+#pragma unroll
+    for (int q = 0; q < WP; ++q) DARK_GLDS16(gw[q] + kt * BK, w + q * 1024);
   };
 
-  f32x4 acc[4][4];  // [ni][mi]
+  f32x4 acc[TNW][4];  // [ni][mi]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TNW; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -339,19 +349,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
   const int frow = lane & 15, fq = lane >> 4;
   const int fsw = (frow >> 1) & 7;
   auto compute = [&](int buf) {
-    const char* as = smem + buf * 2 * TILE + (wm * 64 + frow) * 128;
-    const char* ws = smem + buf * 2 * TILE + TILE + (wn * 64 + frow) * 128;
+    const char* as = smem + buf * STAGE + (wm * 64 + frow) * 128;
+    const char* ws = smem + buf * STAGE + TILE + (wn * WN + frow) * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ch = ((4 * ks + fq) ^ fsw) << 4;
-      bf16x8 af[4], wf[4];
+      bf16x8 af[4], wf[TNW];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *(const bf16x8*)(as + i * 16 * 128 + ch);
-        wf[i] = *(const bf16x8*)(ws + i * 16 * 128 + ch);
-      }
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(as + i * 16 * 128 + ch);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < TNW; ++j) wf[j] = *(const bf16x8*)(ws + j * 16 * 128 + ch);
+#pragma unroll
+      for (int j = 0; j < TNW; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
@@ -373,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
     const bool row_ok = m < M;
     const int64_t mrow = row_ok ? m : 0;
     if constexpr (EPI == EPI_SWIGLU) {
+      static_assert(EPI != EPI_SWIGLU || BNt == 128, "gate/up rows are interleaved in groups of 32");
       float v[2][4];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
@@ -381,12 +391,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
       store_pair_bf16(v[0], v[1], (bf16_t*)out + mrow * ldo, tn * 64 + wn * 32, row_ok ? (N >> 1) : 0, fq, vec_ok);
     } else if constexpr (EPI == EPI_BIAS) {
 #pragma unroll
-      for (int np = 0; np < 2; ++np) {
+      for (int np = 0; np < TNW / 2; ++np) {
         float v[2][4];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int ni = 2 * np + t;
-          const int c = n0 + wn * 64 + ni * 16 + 4 * fq;
+          const int c = n0 + wn * WN + ni * 16 + 4 * fq;
           if (vec_ok && c + 4 <= N) {
             const float4 b4 = *(const float4*)(bias + c);
             v[t][0] = acc[ni][mi][0] + b4.x; v[t][1] = acc[ni][mi][1] + b4.y;
@@ -396,14 +406,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
             for (int e = 0; e < 4; ++e) v[t][e] = acc[ni][mi][e] + (c + e < N ? bias[c + e] : 0.f);
           }
         }
-        store_pair_bf16(v[0], v[1], (bf16_t*)out + mrow * ldo, n0 + wn * 64 + np * 32, row_ok ? N : 0, fq, vec_ok);
+        store_pair_bf16(v[0], v[1], (bf16_t*)out + mrow * ldo, n0 + wn * WN + np * 32, row_ok ? N : 0, fq, vec_ok);
       }
     } else {
       if (!row_ok) continue;
       float* orow = (float*)out + mrow * ldo;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int c = n0 + wn * 64 + ni * 16 + 4 * fq;
+      for (int ni = 0; ni < TNW; ++ni) {
+        const int c = n0 + wn * WN + ni * 16 + 4 * fq;
         if (vec_ok && c + 4 <= N) {
           float4 o = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
           if constexpr (EPI == EPI_RESID) {
@@ -507,6 +517,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------ launch
+template <int EPI, int BNt>
+static int launch_k16(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int64_t ldo,
+                      int vec_ok, hipStream_t st) {
+  constexpr int smem = 2 * (BM + BNt) * 64 * 2;
+  const int tilesM = cdiv(M, BM), tilesN = cdiv(N, BNt);
+  const int nwg = tilesM * tilesN;
+  static bool attr_done = false;
+  if (!attr_done) {
+    DARK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel16<EPI, BNt>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_bf16_kernel16<EPI, BNt>), dim3(nwg), dim3(256), smem, st, (const bf16_t*)A,
+                     (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, nwg, vec_ok);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
 template <int EPI>
 static int launch_epi(int dtype, const void* A, const void* W, const float* bias, void* out, int M, int N,
                       int K, int64_t ldo, hipStream_t st) {
@@ -521,19 +549,24 @@ static int launch_epi(int dtype, const void* A, const void* W, const float* bias
                        ((uintptr_t)out % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
     // MFMA shape per flavour, by sustained measurement on MI355X (tools/gemm_check.py --iters 2000):
     // 16x16x32 wins on the residual, SwiGLU and fp32-out flavours, 32x32x16 on the bias flavour.
-    constexpr bool k16 = EPI != EPI_BIAS;
-    const void* fn = k16 ? (const void*)gemm_bf16_kernel16<EPI> : (const void*)gemm_bf16_kernel<EPI>;
+    if constexpr (EPI == EPI_BIAS) {
+      if (N % 192 == 0) return launch_k16<EPI, 192>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
+    }
+    if constexpr (EPI == EPI_RESID) {
+      // 128 x 192 tiles measure 7 % faster than 128 x 128 at N = 768 (fewer fragment reads per MFMA, 736
+      // instead of 1104 workgroups over the 512 slots)
+      if (N % 192 == 0)
+        return launch_k16<EPI, 192>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
+    }
+    if constexpr (EPI != EPI_BIAS) return launch_k16<EPI, 128>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
     static bool attr_done = false;
     if (!attr_done) {
-      DARK_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      DARK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
       attr_done = true;
     }
-    if constexpr (k16)
-      hipLaunchKernelGGL(gemm_bf16_kernel16<EPI>, dim3(nwg), dim3(256), smem, st, (const bf16_t*)A,
-                         (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, nwg, vec_ok);
-    else
-      hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nwg), dim3(256), smem, st, (const bf16_t*)A,
-                         (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, nwg, vec_ok);
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nwg), dim3(256), smem, st, (const bf16_t*)A,
+                       (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, nwg, vec_ok);
   } else {
     hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nwg), dim3(256), 0, st, (const float*)A,
                        (const float*)W, bias, out, M, N, K, ldo, tilesN, nwg);
