@@ -65,17 +65,20 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const float*
 
 // ------------------------------------------------------------------ bf16
 // Operands are SWAPPED in the MFMA (srcA = weight fragment, srcB = activation fragment), so the
-// accumulator holds D[n][m]: a lane owns ONE output row m = lane & 31 and, per 32x32 tile, the columns
-// n = 8g + 4h + e (g = reg >> 2, h = lane >> 5, e = reg & 3): four consecutive columns per register
-// group, which makes the epilogue a row-per-lane store of 16-B pieces (bf16 after one permlane32_swap
-// per register pair, fp32 directly) instead of 2-byte column-strided stores.
+// accumulator holds D[n][m]: a lane owns ONE output row m = lane & 15 and, per 16x16 tile, the four
+// consecutive columns 4*(lane >> 4) + e, which makes the epilogue a row-per-lane store of 16-B pieces (bf16
+// after one permlane16_swap per dword, fp32 directly) instead of 2-byte column-strided stores.
 //
 // Staging: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip).  The LDS image of an operand tile is
-// lane-linear ([128 rows][8 chunks of 16 B]); the XOR swizzle that makes the ds_read_b128 fragment reads
+// lane-linear ([rows][8 chunks of 16 B]); the XOR swizzle that makes the ds_read_b128 fragment reads
 // conflict-free (physical chunk = logical chunk ^ ((row >> 1) & 7): 16 rows of a read group land on the 16
 // distinct 16-B slots of the 256-B bank row) is applied to the per-lane SOURCE address.
 // Pipeline: 2 LDS stages, one barrier per K tile; the DMA of tile t+1 is in flight during the MFMAs of
-// tile t; 64 KiB LDS -> 2 workgroups per CU, so the other workgroup's MFMAs cover this one's barrier.
+// tile t; <= 80 KiB LDS -> 2 workgroups per CU, so the other workgroup's MFMAs cover this one's barrier.
+//
+// Tried and dropped (measured on MI355X): a 32x32x16-MFMA twin of this kernel (4-8 % slower
+// under sustained load), a 256x256 4-stage LDS-DMA ring with counted vmcnt (no gain at K = 768), and folding
+// the RMSNorms into the GEMM epilogues (the GEMMs slowed down by more than the norm passes cost).
 #define DARK_GLDS16(gsrc, ldst)                                                                  \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),         \
                                    (__attribute__((address_space(3))) void*)(ldst), 16, 0, 0)
@@ -86,175 +89,6 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   v[0] = (bf16_t)lo;
   v[1] = (bf16_t)hi;
   return __builtin_bit_cast(uint32_t, v);
-}
-
-// v[16]: one 32x32 tile of final fp32 values of this lane (row m, columns cb + 8g + 4h + e), stored as bf16
-__device__ __forceinline__ void store_tile_bf16(const float (&v)[16], bf16_t* __restrict__ orow, int cb, int ncols,
-                                                int h, bool row_ok, bool vec_ok) {
-  uint32_t lo[4], hi[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    lo[g] = pack_bf16x2(v[4 * g], v[4 * g + 1]);
-    hi[g] = pack_bf16x2(v[4 * g + 2], v[4 * g + 3]);
-  }
-  if (vec_ok) {
-#pragma unroll
-    for (int g = 0; g < 4; g += 2) {
-      // lanes 0-31 end up with columns 8g..8g+7, lanes 32-63 with 8(g+1)..8(g+1)+7
-      const auto sx = __builtin_amdgcn_permlane32_swap(lo[g], lo[g + 1], false, false);
-      const auto sy = __builtin_amdgcn_permlane32_swap(hi[g], hi[g + 1], false, false);
-      const int c = cb + 8 * (g + h);
-      if (row_ok && c + 8 <= ncols) *(uint4*)(orow + c) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-    }
-  } else if (row_ok) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c = cb + 8 * g + 4 * h;
-      const uint32_t w[2] = {lo[g], hi[g]};
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (c + e < ncols) ((uint16_t*)orow)[c + e] = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
-    }
-  }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
-                                                           const bf16_t* __restrict__ W,
-                                                           const float* __restrict__ bias,
-                                                           void* __restrict__ out, int M, int N, int K,
-                                                           int64_t ldo, int tilesM, int tilesN, int nwg,
-                                                           int vec_ok) {
-  constexpr int BK = 64;
-  constexpr int TILE = BM * BK * 2;  // 16 KiB per operand tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage][A | W]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-contiguous chunk of the tile space, then groups of GM row panels swept column by column: the
-  // ~64 tiles resident on one XCD share GM activation panels and ~64/GM weight panels through its L2
-  constexpr int GM = 8;
-  const int wg = xcd_remap(blockIdx.x, nwg);
-  const int per_group = GM * tilesN;
-  const int group = wg / per_group;
-  const int first_m = group * GM;
-  const int gsz = min(GM, tilesM - first_m);
-  const int rem = wg - group * per_group;
-  const int tn = rem / gsz, tm = first_m + (rem - tn * gsz);
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  // staging: wave w fills rows [32w, 32w+32) of both operand tiles, 4 pieces of 8 rows x 128 B each
-  const bf16_t* ga[4];
-  const bf16_t* gw[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = wave * 32 + q * 8 + (lane >> 3);
-    const int lch = (lane & 7) ^ ((row >> 1) & 7);  // logical 16-B chunk this lane's LDS slot must hold
-    int ar = m0 + row;
-    ar = ar < M ? ar : M - 1;
-    ga[q] = A + (int64_t)ar * K + lch * 8;
-    gw[q] = W + (int64_t)(n0 + row) * K + lch * 8;
-  }
-  char* const lstage = smem + wave * 4096;
-  auto stage = [&](int buf, int kt) {
-    char* a = lstage + buf * 2 * TILE;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      DARK_GLDS16(ga[q] + kt * BK, a + q * 1024);
-      DARK_GLDS16(gw[q] + kt * BK, a + TILE + q * 1024);
-    }
-  };
-
-  f32x16 acc[2][2];  // [ni][mi]
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int KT = K / BK;
-  const int frow = lane & 31, fh = lane >> 5;
-  const int fsw = (frow >> 1) & 7;
-  auto compute = [&](int buf) {
-    const char* as = smem + buf * 2 * TILE + (wm * 64 + frow) * 128;
-    const char* ws = smem + buf * 2 * TILE + TILE + (wn * 64 + frow) * 128;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int ch = ((2 * kk + fh) ^ fsw) << 4;
-      const bf16x8 a0 = *(const bf16x8*)(as + ch);
-      const bf16x8 a1 = *(const bf16x8*)(as + 32 * 128 + ch);
-      const bf16x8 w0 = *(const bf16x8*)(ws + ch);
-      const bf16x8 w1 = *(const bf16x8*)(ws + 32 * 128 + ch);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, acc[1][1], 0, 0, 0);
-    }
-  };
-
-  stage(0, 0);
-  for (int kt = 0; kt < KT; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt have landed
-    __syncthreads();                                   // everyone's have; buffer (kt+1)&1 is no longer read
-    if (kt + 1 < KT) stage((kt + 1) & 1, kt + 1);
-    compute(kt & 1);
-  }
-
-  // ---- epilogue: lane owns row m, columns 8g + 4h + e of each 32x32 tile
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = m0 + wm * 64 + mi * 32 + frow;
-    const bool row_ok = m < M;
-    const int64_t mrow = row_ok ? m : 0;
-    if constexpr (EPI == EPI_SWIGLU) {
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = silu_fast(acc[0][mi][r]) * acc[1][mi][r];
-      store_tile_bf16(v, (bf16_t*)out + mrow * ldo, tn * 64 + wn * 32, N >> 1, fh, row_ok, vec_ok);
-    } else {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int nb = n0 + wn * 64 + ni * 32;
-        if constexpr (EPI == EPI_BIAS) {
-          float v[16];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const float4 b4 = *(const float4*)(bias + nb + 8 * g + 4 * fh);  // bias is padded like W's rows
-            v[4 * g] = acc[ni][mi][4 * g] + b4.x;
-            v[4 * g + 1] = acc[ni][mi][4 * g + 1] + b4.y;
-            v[4 * g + 2] = acc[ni][mi][4 * g + 2] + b4.z;
-            v[4 * g + 3] = acc[ni][mi][4 * g + 3] + b4.w;
-          }
-          store_tile_bf16(v, (bf16_t*)out + mrow * ldo, nb, N, fh, row_ok, vec_ok);
-        } else {
-          float* orow = (float*)out + mrow * ldo;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int c = nb + 8 * g + 4 * fh;
-            if (!row_ok) continue;
-            if (vec_ok && c + 4 <= N) {
-              float4 o = make_float4(acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2],
-                                     acc[ni][mi][4 * g + 3]);
-              if constexpr (EPI == EPI_RESID) {
-                const float4 p = *(const float4*)(orow + c);
-                o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-              }
-              *(float4*)(orow + c) = o;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                if (c + e >= N) continue;
-                if constexpr (EPI == EPI_RESID) orow[c + e] += acc[ni][mi][4 * g + e];
-                else orow[c + e] = acc[ni][mi][4 * g + e];
-              }
-            }
-          }
-        }
-      }
-    }
-  }
 }
 
 // Two horizontally adjacent 16x16 tiles of final values of this lane (row m; tile t holds columns
@@ -283,9 +117,7 @@ __device__ __forceinline__ void store_pair_bf16(const float (&v0)[4], const floa
 }
 
 // ------------------------------------------------------------------ bf16, 16x16x32 MFMA shape
-// Same tile, staging and pipeline as gemm_bf16_kernel; the wave's 64x64 block is 4x4 tiles of
-// v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on this shape under sustained load).
-// Accumulator map (operands swapped): lane owns row m = lane & 15 and columns 4*(lane>>4) + e of a tile.
+// 128 x BNt block tile, 4 waves (2x2), each wave 64 x BNt/2 = 4 x TNW tiles of v_mfma_f32_16x16x32_bf16.
 // BNt = 128, or 192 for the N = 768 GEMMs: 184 x 4 tiles fill 512 workgroup slots 2.9 times instead of 4.3
 // (96 % instead of 86 % tile quantisation at M = 23552) and cut the fragment reads per MFMA from 0.5 to 0.42.
 template <int EPI, int BNt>
@@ -541,32 +373,18 @@ static int launch_epi(int dtype, const void* A, const void* W, const float* bias
   const int tilesM = cdiv(M, BM), tilesN = cdiv(N, BN);
   const int nwg = tilesM * tilesN;
   if (dtype == DARK_BF16) {
-    constexpr int smem = 4 * BM * 64 * 2;  // 64 KiB
     // 16-B row pieces need 16-B aligned rows: bf16 outputs 8 elements, fp32 outputs 4
     const int per16 = (EPI == EPI_BIAS || EPI == EPI_SWIGLU) ? 8 : 4;
     const int ncols = EPI == EPI_SWIGLU ? N / 2 : N;
     const int vec_ok = (ldo % per16 == 0) && (ncols % per16 == 0) &&
                        ((uintptr_t)out % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
-    // MFMA shape per flavour, by sustained measurement on MI355X (tools/gemm_check.py --iters 2000):
-    // 16x16x32 wins on the residual, SwiGLU and fp32-out flavours, 32x32x16 on the bias flavour.
-    if constexpr (EPI == EPI_BIAS) {
+    // 128 x 192 tiles where the column count allows (and the gate/up interleave does not forbid it): fewer
+    // fragment reads per MFMA and, at N = 768, 736 instead of 1104 workgroups over the 512 slots; measured
+    // +7 % on the residual GEMMs, +2 % on qkv (tools/gemm_check.py --iters 2000)
+    if constexpr (EPI == EPI_RESID || EPI == EPI_BIAS) {
       if (N % 192 == 0) return launch_k16<EPI, 192>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
     }
-    if constexpr (EPI == EPI_RESID) {
-      // 128 x 192 tiles measure 7 % faster than 128 x 128 at N = 768 (fewer fragment reads per MFMA, 736
-      // instead of 1104 workgroups over the 512 slots)
-      if (N % 192 == 0)
-        return launch_k16<EPI, 192>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
-    }
-    if constexpr (EPI != EPI_BIAS) return launch_k16<EPI, 128>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
-    static bool attr_done = false;
-    if (!attr_done) {
-      DARK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(nwg), dim3(256), smem, st, (const bf16_t*)A,
-                       (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, nwg, vec_ok);
+    return launch_k16<EPI, 128>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
   } else {
     hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nwg), dim3(256), 0, st, (const float*)A,
                        (const float*)W, bias, out, M, N, K, ldo, tilesN, nwg);
