@@ -214,13 +214,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
     const bool row_ok = m < M;
     const int64_t mrow = row_ok ? m : 0;
     if constexpr (EPI == EPI_SWIGLU) {
-      static_assert(EPI != EPI_SWIGLU || BNt == 128, "gate/up rows are interleaved in groups of 32");
-      float v[2][4];
+      // bf16 packing interleaves gate/up rows in groups of 16: MFMA tiles 2p / 2p+1 are gate / up of the
+      // 16 output columns (n0 + wn*WN)/2 + 16p ..
+      constexpr int TO = TNW / 2;
+      float v[TO][4];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int p = 0; p < TO; ++p)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[ni][e] = silu_fast(acc[ni][mi][e]) * acc[ni + 2][mi][e];
-      store_pair_bf16(v[0], v[1], (bf16_t*)out + mrow * ldo, tn * 64 + wn * 32, row_ok ? (N >> 1) : 0, fq, vec_ok);
+        for (int e = 0; e < 4; ++e) v[p][e] = silu_fast(acc[2 * p][mi][e]) * acc[2 * p + 1][mi][e];
+      bf16_t* orow = (bf16_t*)out + mrow * ldo;
+      const int cb = (n0 + wn * WN) >> 1, nout = row_ok ? (N >> 1) : 0;
+#pragma unroll
+      for (int p = 0; p + 1 < TO; p += 2) store_pair_bf16(v[p], v[p + 1], orow, cb + 16 * p, nout, fq, vec_ok);
+      if constexpr (TO & 1) {
+        const int c = cb + 16 * (TO - 1) + 4 * fq;
+        if (vec_ok && c + 4 <= nout) {
+          *(uint2*)(orow + c) = make_uint2(pack_bf16x2(v[TO - 1][0], v[TO - 1][1]), pack_bf16x2(v[TO - 1][2], v[TO - 1][3]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < nout) orow[c + e] = (bf16_t)v[TO - 1][e];
+        }
+      }
     } else if constexpr (EPI == EPI_BIAS) {
 #pragma unroll
       for (int np = 0; np < TNW / 2; ++np) {
@@ -378,13 +393,12 @@ static int launch_epi(int dtype, const void* A, const void* W, const float* bias
     const int ncols = EPI == EPI_SWIGLU ? N / 2 : N;
     const int vec_ok = (ldo % per16 == 0) && (ncols % per16 == 0) &&
                        ((uintptr_t)out % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
-    // 128 x 192 tiles where the column count allows (and the gate/up interleave does not forbid it): fewer
-    // fragment reads per MFMA and, at N = 768, 736 instead of 1104 workgroups over the 512 slots; measured
-    // +7 % on the residual GEMMs, +2 % on qkv (tools/gemm_check.py --iters 2000)
-    if constexpr (EPI == EPI_RESID || EPI == EPI_BIAS) {
-      if (N % 192 == 0) return launch_k16<EPI, 192>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
-    }
-    return launch_k16<EPI, 128>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
+    // 128 x 192 tiles: fewer fragment reads per MFMA than 128 x 128 and, at N = 768, 736 instead of 1104
+    // workgroups over the 512 slots; measured +7..9 % on the residual GEMMs, +5 % on gate/up and qkv
+    // (tools/gemm_check.py --iters 2000).  Edge tiles clamp their operand rows, so any N works.
+    // The fp32-out flavour (LM head, N = 15080) measures 6 % faster on 128-wide tiles.
+    if constexpr (EPI == EPI_F32) return launch_k16<EPI, 128>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
+    else return launch_k16<EPI, 192>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
   } else {
     hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nwg), dim3(256), 0, st, (const float*)A,
                        (const float*)W, bias, out, M, N, K, ldo, tilesN, nwg);
@@ -460,7 +474,7 @@ static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, co
       return launch_epi<EPI_BIAS>(dtype, A, W, bias, out, M, N, K, ldo, st);
     case EPI_RESID: return launch_epi<EPI_RESID>(dtype, A, W, bias, out, M, N, K, ldo, st);
     case EPI_SWIGLU:
-      DARK_CHECK_ARG(N % 64 == 0, "gemm: SWIGLU needs N %% 64 == 0 (N=%d)", N);
+      DARK_CHECK_ARG(N % 32 == 0, "gemm: SWIGLU needs N %% 32 == 0 (N=%d)", N);
       return launch_epi<EPI_SWIGLU>(dtype, A, W, bias, out, M, N, K, ldo, st);
     case EPI_F32: return launch_epi<EPI_F32>(dtype, A, W, bias, out, M, N, K, ldo, st);
   }

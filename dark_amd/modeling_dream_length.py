@@ -49,12 +49,17 @@ def _pad_rows(w: torch.Tensor, mult: int = _TILE) -> torch.Tensor:
     return torch.cat([w, w.new_zeros((r,) + tuple(w.shape[1:]))], dim=0).contiguous()
 
 
-def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
-    """[ff,d],[ff,d] -> [2ff,d]: rows [64g,64g+32) = gate[32g:32g+32], [64g+32,64g+64) = up[32g:32g+32]
-    (the fused SwiGLU epilogue wants gate and up of one output column in the same lane)."""
+def gate_up_group(dtype: torch.dtype) -> int:
+    """Interleave granularity of w_gu = the MFMA tile width of the GEMM kernel of that dtype."""
+    return 16 if dtype == torch.bfloat16 else 32
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor, group: int = 32) -> torch.Tensor:
+    """[ff,d],[ff,d] -> [2ff,d]: rows [2Gj, 2Gj+G) = gate[Gj:Gj+G], [2Gj+G, 2Gj+2G) = up[Gj:Gj+G], G = group
+    (the fused SwiGLU epilogue wants gate and up of one output column in the same lane: adjacent MFMA tiles)."""
     ff, d = gate.shape
-    assert ff % 32 == 0
-    return torch.stack([gate.view(ff // 32, 32, d), up.view(ff // 32, 32, d)], dim=1).reshape(2 * ff, d)
+    assert ff % group == 0
+    return torch.stack([gate.view(ff // group, group, d), up.view(ff // group, group, d)], dim=1).reshape(2 * ff, d)
 
 
 def rope_tables(head_dim: int, theta: float, max_pos: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -97,7 +102,8 @@ class PackedWeights:
             lw.b_qkv = dev(_pad_rows(b_qkv), torch.float32).data_ptr()
             lw.w_o = dev(_pad_rows(sd[a + "o_proj.weight"])).data_ptr()
             lw.w_gu = dev(_pad_rows(interleave_gate_up(sd[p + "mlp.gate_proj.weight"],
-                                                       sd[p + "mlp.up_proj.weight"]))).data_ptr()
+                                                       sd[p + "mlp.up_proj.weight"],
+                                                       gate_up_group(dtype)))).data_ptr()
             lw.w_down = dev(_pad_rows(sd[p + "mlp.down_proj.weight"])).data_ptr()
             lw.ln1 = dev(sd[p + "input_layernorm.weight"], torch.float32).data_ptr()
             lw.ln2 = dev(sd[p + "post_attention_layernorm.weight"], torch.float32).data_ptr()

@@ -48,8 +48,8 @@ typedef struct dark_layer_weights {
   const void* w_qkv;   /* [3d, d]: q rows, then k rows, then v rows                        */
   const float* b_qkv;  /* [3d] fp32                                                        */
   const void* w_o;     /* [d, d]                                                           */
-  const void* w_gu;    /* [2ff, d]: gate/up interleaved in groups of 32 output columns:    *
-                        * rows [64g, 64g+32) = gate[32g..], rows [64g+32, 64g+64) = up[32g..] */
+  const void* w_gu;    /* [2ff, d]: gate/up interleaved in groups of G output columns (G = 16 for bf16, 32  *
+                        * for fp32): rows [2Gj, 2Gj+G) = gate[Gj..], rows [2Gj+G, 2Gj+2G) = up[Gj..]        */
   const void* w_down;  /* [d, ff]                                                          */
   const float* ln1;    /* input_layernorm.weight [d] fp32                                  */
   const float* ln2;    /* post_attention_layernorm.weight [d] fp32                         */
@@ -152,7 +152,7 @@ int dark_prof_read(double* total_ms, double* total_flops, int* launches);
 /* ---- unit-test hooks (no counterpart in the reference): launch ONE kernel of the path so that
  * tests/test_hip_kernels.py can pin it against the oracle in isolation.
  *   epi: 0 = +bias (out in model dtype), 1 = residual add into fp32 out, 2 = SwiGLU over interleaved
- *        gate/up rows (out [M, N/2] model dtype), 3 = plain fp32 store.  W has rows padded to 128. */
+ *        gate/up rows, groups of 16 (bf16) / 32 (fp32) (out [M, N/2] model dtype), 3 = plain fp32 store.  W has rows padded to 128. */
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                   int N, int K, int64_t ldo, void* stream);
 int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,

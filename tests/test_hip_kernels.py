@@ -73,7 +73,7 @@ def test_gemm_plain_and_bias(lib, dtype, M, N, K):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_resid_and_swiglu(lib, dtype):
     H = _hip()
-    from dark_amd.modeling_dream_length import interleave_gate_up
+    from dark_amd.modeling_dream_length import gate_up_group, interleave_gate_up
     g = torch.Generator().manual_seed(5)
     M, d, ff = 333, 192, 384
     A = torch.randn(M, ff, generator=g).to(dtype)
@@ -89,7 +89,7 @@ def test_gemm_resid_and_swiglu(lib, dtype):
     X = torch.randn(M, d, generator=g).to(dtype)
     Wg = (torch.randn(ff, d, generator=g) * 0.1).to(dtype)
     Wu = (torch.randn(ff, d, generator=g) * 0.1).to(dtype)
-    Wgu = _pad_rows(interleave_gate_up(Wg, Wu)).to(DEV)
+    Wgu = _pad_rows(interleave_gate_up(Wg, Wu, gate_up_group(dtype))).to(DEV)
     act = torch.zeros(M, ff, device=DEV, dtype=dtype)
     Xd = X.to(DEV)
     H.check(lib.dark_dbg_gemm(_dt(dtype), 2, H.ptr(Xd), H.ptr(Wgu), None, H.ptr(act), M, 2 * ff, d, ff, _s()))

@@ -56,7 +56,7 @@ def main():
             ldo = N
         elif epi == 2:
             Wg, Wu = W[: N // 2], W[N // 2:]
-            Wd = pad_rows(interleave_gate_up(Wg, Wu)).to(dev)
+            Wd = pad_rows(interleave_gate_up(Wg, Wu, 16)).to(dev)
             gg, uu = A.double() @ Wg.double().t(), A.double() @ Wu.double().t()
             ref = torch.nn.functional.silu(gg) * uu
             out = torch.zeros(M, N // 2, device=dev, dtype=torch.bfloat16)
