@@ -8,7 +8,9 @@
 // Nucleus filter without a sort: the kept set of top_p_logits is the prefix of the descending order
 // up to and including the first element whose inclusive cumulative probability exceeds top_p.  All
 // cumulative sums are integers (probability MASS in 2^-40 fixed point), so they are order independent
-// and deterministic.  The crossing element is found in two stages:
+// and deterministic.  Peaked rows take a head path: the elements within 6 of the row maximum are gathered in
+// the pass that sums the masses, and if they hold more than top_p of the mass the crossing is resolved among
+// them directly.  Otherwise the crossing element is found in two stages:
 //   1. one histogram pass over bins that are LINEAR in (row max - logit), 28/1023 wide (mass is 0 beyond 27.7),
 //      so the row spreads over the bins and the LDS atomics do not pile up on a few addresses; the bin
 //      map is monotone in the logit, hence bins are contiguous ranges of the descending order;
@@ -26,7 +28,8 @@ namespace dark {
 constexpr int ST = 512;         // threads per row (8 waves)
 constexpr int NLIN = 1024;      // linear bins of stage 1
 constexpr int NRAD = 256;       // radix bins of the fallback select
-constexpr int CAND_CAP = 1024;  // elements of the crossing bin resolved exactly
+constexpr int CAND_CAP = ST;         // candidates resolved exactly, one per thread
+constexpr float HEAD_RANGE = 6.0f;    // head path: candidates are the logits within this of the row maximum
 constexpr float LIN_RANGE = 28.0f;
 #define DARK_FLT_LOWEST (-3.4028234663852886e38f)  // torch.finfo(torch.float32).min
 
@@ -203,25 +206,86 @@ __device__ bool select_crossing(const float* row, int V, float mx, unsigned long
   return true;
 }
 
-// Stage 1 + 2 of the nucleus search (see the header).  Returns 1 = found, 0 = no crossing (nothing to
-// filter), -1 = the crossing bin overflows CAND_CAP (caller falls back to the radix select).
-__device__ int nucleus_crossing(const float* row, int V, float mx, unsigned long long* Zout, float top_p,
-                                unsigned long long* hist, uint32_t* cand, Scratch* s, int tid, uint32_t* tau,
-                                unsigned long long* above, int* n_tau, unsigned long long* Tout) {
-  for (int i = tid; i < NLIN; i += ST) hist[i] = 0;
+// Exact resolution among c gathered candidates (keys cand[], fixed-point masses cfx[]) that form a contiguous
+// range of the descending order with mass A strictly above it: tau = the largest key whose inclusive
+// cumulative mass exceeds T.  Returns 1 and *tau / *above (mass of keys > tau) / *n_tau (multiplicity), or 0.
+__device__ int resolve_candidates(const uint32_t* cand, const unsigned long long* cfx, int c, unsigned long long A,
+                                  unsigned long long T, Scratch* s, int tid, uint32_t* tau,
+                                  unsigned long long* above, int* n_tau) {
+  // c <= CAND_CAP = ST: thread j owns candidate j and sums the masses of all candidates not below it
+  const bool own = tid < c;
+  const uint32_t kj = own ? cand[tid] : 0u;
+  const unsigned long long fj = own ? cfx[tid] : 0ull;
+  unsigned long long S = A;
+  const int c4 = c & ~3;
+  for (int i = 0; i < c4; i += 4) {  // broadcast LDS reads, independent of each other: issued back to back
+    const uint32_t k0 = cand[i], k1 = cand[i + 1], k2 = cand[i + 2], k3 = cand[i + 3];
+    const unsigned long long f0 = cfx[i], f1 = cfx[i + 1], f2 = cfx[i + 2], f3 = cfx[i + 3];
+    S += (k0 >= kj ? f0 : 0ull) + (k1 >= kj ? f1 : 0ull) + (k2 >= kj ? f2 : 0ull) + (k3 >= kj ? f3 : 0ull);
+  }
+  for (int i = c4; i < c; ++i) S += cand[i] >= kj ? cfx[i] : 0ull;
+  const uint32_t best = block_max_u32((own && S > T) ? kj : 0u, s, tid);
+  if (best == 0) return 0;
+  // mass strictly above tau and the multiplicity of tau, again one candidate per thread
+  const unsigned long long ab = block_sum_u64((own && kj > best) ? fj : 0ull, s, tid);
+  const unsigned long long nt = block_sum_u64((own && kj == best) ? 1ull : 0ull, s, tid);
+  *tau = best;
+  *above = A + ab;
+  *n_tau = (int)nt;
+  return 1;
+}
+
+// The nucleus search (see the header).  Returns 1 = found, 0 = no crossing (nothing to filter), -1 = the
+// crossing bin overflows CAND_CAP (caller falls back to the radix select).
+// *head_c: number of gathered head candidates when the head path resolved the crossing (every kept element is
+// then one of cand[0..c) / cidx[0..c)), -1 otherwise.
+__device__ int nucleus_crossing(const float* row, int V, float mx, float top_p, unsigned long long* hist,
+                                uint32_t* cand, unsigned long long* cfx, int* cidx, Scratch* s, int tid,
+                                uint32_t* tau, unsigned long long* above, int* n_tau, unsigned long long* Tout,
+                                int* head_c) {
+  *head_c = -1;
+  // ---- head path: the pass that sums the masses also gathers the elements within HEAD_RANGE of the
+  // maximum; when they hold more than top_p of the mass (any peaked row) the crossing is among them
   if (tid == 0) s->ncand = 0;
   __syncthreads();
   unsigned long long zl = 0;
+  int mine = 0;  // a thread gathers at most 2 of its ~V/512 elements: a flat row overflows after <= 1024 atomics
   for (int i = tid; i < V; i += ST) {
     const float l = row[i];
     const unsigned long long fx = mass_fx(l, mx);
     zl += fx;
+    if (l - mx > -HEAD_RANGE) {
+      if (mine < 2) {
+        const int slot = atomicAdd(&s->ncand, 1);
+        if (slot < CAND_CAP) { cand[slot] = fkey(l); cfx[slot] = fx; cidx[slot] = i; }
+      } else if (mine == 2) {
+        atomicAdd(&s->ncand, CAND_CAP + 1);  // poison the count: the head set is incomplete
+      }
+      ++mine;
+    }
+  }
+  const unsigned long long Z = block_sum_u64(zl, s, tid);  // (its barriers also publish the candidates)
+  const unsigned long long T = (unsigned long long)((double)top_p * (double)Z);  // floor
+  *Tout = T;
+  int c = s->ncand;
+  if (c <= CAND_CAP) {
+    unsigned long long ml = 0;
+    for (int j = tid; j < c; j += ST) ml += cfx[j];
+    if (block_sum_u64(ml, s, tid) > T) {
+      *head_c = c;
+      return resolve_candidates(cand, cfx, c, 0ull, T, s, tid, tau, above, n_tau);
+    }
+  }
+  // ---- general path: mass histogram over linear bins, then the elements of the crossing bin
+  for (int i = tid; i < NLIN; i += ST) hist[i] = 0;
+  __syncthreads();
+  if (tid == 0) s->ncand = 0;
+  for (int i = tid; i < V; i += ST) {
+    const float l = row[i];
+    const unsigned long long fx = mass_fx(l, mx);
     if (fx) atomicAdd(&hist[lin_bin(l, mx)], fx);
   }
-  const unsigned long long Z = block_sum_u64(zl, s, tid);  // (its barriers also publish the histogram)
-  const unsigned long long T = (unsigned long long)((double)top_p * (double)Z);  // floor
-  *Zout = Z;
-  *Tout = T;
+  __syncthreads();
   scan_crossing(hist, NLIN, 0, +1, 0ull, T, s, tid);
   __syncthreads();
   if (!s->found) return 0;
@@ -231,41 +295,13 @@ __device__ int nucleus_crossing(const float* row, int V, float mx, unsigned long
     const float l = row[i];
     if (lin_bin(l, mx) == b) {
       const int slot = atomicAdd(&s->ncand, 1);
-      if (slot < CAND_CAP) cand[slot] = fkey(l);
+      if (slot < CAND_CAP) { cand[slot] = fkey(l); cfx[slot] = mass_fx(l, mx); }
     }
   }
   __syncthreads();
-  const int c = s->ncand;
+  c = s->ncand;
   if (c > CAND_CAP) return -1;
-  // exact resolution: tau = the largest candidate key whose inclusive cumulative mass exceeds T
-  uint32_t best = 0;
-  for (int j = tid; j < c; j += ST) {
-    const uint32_t kj = cand[j];
-    unsigned long long S = A;
-    for (int i = 0; i < c; ++i) {
-      const uint32_t ki = cand[i];
-      if (ki >= kj) S += mass_fx(fkey_inv(ki), mx);
-    }
-    if (S > T) best = max(best, kj);
-  }
-  best = block_max_u32(best, s, tid);
-  if (best == 0) return 0;  // cannot happen when the bin scan found a crossing; be safe
-  if (tid == 0) {
-    unsigned long long S = A;
-    int n = 0;
-    for (int i = 0; i < c; ++i) {
-      const uint32_t ki = cand[i];
-      if (ki > best) S += mass_fx(fkey_inv(ki), mx);
-      n += ki == best;
-    }
-    s->above = S;
-    s->bin = n;
-  }
-  __syncthreads();
-  *tau = best;
-  *above = s->above;
-  *n_tau = s->bin;
-  return 1;
+  return resolve_candidates(cand, cfx, c, A, T, s, tid, tau, above, n_tau);
 }
 
 __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ logits, int64_t ldl, int V,
@@ -277,8 +313,10 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   float* row = (float*)smem;
   unsigned long long* hist = (unsigned long long*)(smem + (size_t)vp * 4);  // NLIN u64; radix hist/cnt alias it
   unsigned int* cnth = (unsigned int*)(hist + NRAD);
-  uint32_t* cand = (uint32_t*)(hist + NLIN);
-  Scratch* s = (Scratch*)(cand + CAND_CAP);
+  unsigned long long* cfx = hist + NLIN;
+  uint32_t* cand = (uint32_t*)(cfx + CAND_CAP);
+  int* cidx = (int*)(cand + CAND_CAP);
+  Scratch* s = (Scratch*)(cidx + CAND_CAP);
   const int tid = threadIdx.x;
   const int m = blockIdx.x;
   const float* lr = logits + (int64_t)m * ldl;
@@ -309,17 +347,40 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   }
   mx = block_max(mx, s, tid);
 
+  int list_c = -1;   // >= 0: list mode (see below)
+  int my_idx = 0;    // list mode: vocabulary index of this thread's candidate
+  float my_e = 0.f;  // list mode: exp(l - max) of this thread's candidate if it is kept, else 0
+
   // 2. nucleus filter (generation_utils.py:37-48)
   if (top_p > 0.f && top_p < 1.f) {
     uint32_t tau = 0;
-    unsigned long long above = 0, Z = 0, T = 0;
+    unsigned long long above = 0, T = 0;
     int n_tau = 0;
-    int rc = nucleus_crossing(row, V, mx, &Z, top_p, hist, cand, s, tid, &tau, &above, &n_tau, &T);
+    int head_c = -1;
+    int rc = nucleus_crossing(row, V, mx, top_p, hist, cand, cfx, cidx, s, tid, &tau, &above, &n_tau, &T, &head_c);
     if (rc < 0) rc = select_crossing<true>(row, V, mx, T, hist, cnth, s, tid, &tau, &above, &n_tau) ? 1 : 0;
     if (rc > 0) {
       const unsigned long long fx = mass_fx(fkey_inv(tau), mx);
       unsigned long long t_keep = fx ? (T - above) / fx + 1ull : (unsigned long long)n_tau;
-      if (t_keep >= (unsigned long long)n_tau) {
+      if (head_c >= 0 && !(top_k > 0 && top_k < V)) {
+        // list mode: the kept set lies inside the gathered head candidates, one per thread; the softmax,
+        // confidence and draw below run on that list and the row is never rewritten or rescanned
+        list_c = head_c;
+        if (tid < head_c) {
+          const uint32_t kj = cand[tid];
+          my_idx = cidx[tid];
+          bool keep = kj > tau;
+          if (kj == tau) {
+            keep = true;
+            if (t_keep < (unsigned long long)n_tau) {  // only the first t_keep (by index) of the equal logits stay
+              unsigned long long rank = 0;
+              for (int i = 0; i < head_c; ++i) rank += (cand[i] == tau && cidx[i] < my_idx);
+              keep = rank < t_keep;
+            }
+          }
+          if (keep) my_e = exp_neg(fkey_inv(kj) - mx);
+        }
+      } else if (t_keep >= (unsigned long long)n_tau) {
         for (int i = tid; i < V; i += ST)
           if (fkey(row[i]) < tau) row[i] = DARK_FLT_LOWEST;
       } else {
@@ -368,15 +429,20 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   // below, so the passes from here on only do work for the kept set: the branches are
   // wave-uniform-false for almost every wave of a filtered row, and the noise row is only touched at the
   // kept positions.
+  const bool list = list_c >= 0;
   double zs = 0.0;
-  for (int i = tid; i < V; i += ST) {
-    const float d = row[i] - mx;
-    float e = 0.f;
-    if (d > -104.f) {  // exp(-104) < 2^-149: exactly 0 in fp32 below
-      e = exp_neg(d);
-      zs += (double)e;
+  if (list) {
+    zs = (double)my_e;
+  } else {
+    for (int i = tid; i < V; i += ST) {
+      const float d = row[i] - mx;
+      float e = 0.f;
+      if (d > -104.f) {  // exp(-104) < 2^-149: exactly 0 in fp32 below
+        e = exp_neg(d);
+        zs += (double)e;
+      }
+      row[i] = e;
     }
-    row[i] = e;
   }
   const float Zf = (float)block_sum(zs, s, tid);
 
@@ -384,15 +450,27 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   float t1 = -INFINITY, t2 = -INFINITY;  // two largest probabilities
   float bestp = -INFINITY;
   int besti = 0x7fffffff;
-  for (int i = tid; i < V; i += ST) {
-    const float e = row[i];
-    if (e > 0.f) {
-      const float p = e / Zf;
-      row[i] = p;
-      ps += (double)p;
-      if (conf_mode == DARK_CONF_NEG_ENTROPY) ent += (double)(p * log_pos(p + 1e-10f));
-      if (p > t1) { t2 = t1; t1 = p; } else if (p > t2) { t2 = p; }
-      if (p > bestp) { bestp = p; besti = i; }
+  float my_p = 0.f;
+  if (list) {
+    if (my_e > 0.f) {
+      my_p = my_e / Zf;
+      ps = (double)my_p;
+      if (conf_mode == DARK_CONF_NEG_ENTROPY) ent = (double)(my_p * log_pos(my_p + 1e-10f));
+      t1 = my_p;
+      bestp = my_p;
+      besti = my_idx;
+    }
+  } else {
+    for (int i = tid; i < V; i += ST) {
+      const float e = row[i];
+      if (e > 0.f) {
+        const float p = e / Zf;
+        row[i] = p;
+        ps += (double)p;
+        if (conf_mode == DARK_CONF_NEG_ENTROPY) ent += (double)(p * log_pos(p + 1e-10f));
+        if (p > t1) { t2 = t1; t1 = p; } else if (p > t2) { t2 = p; }
+        if (p > bestp) { bestp = p; besti = i; }
+      }
     }
   }
   block_sum2(ps, ent, s, tid);
@@ -404,11 +482,15 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
     const float* qr = noise + (int64_t)m * ldn;
     bestp = -INFINITY;
     besti = 0x7fffffff;
-    for (int i = tid; i < V; i += ST) {
-      const float p = row[i];
-      if (p > 0.f) {
-        const float r = (p / psum) / qr[i];
-        if (r > bestp) { bestp = r; besti = i; }
+    if (list) {
+      if (my_p > 0.f) { bestp = (my_p / psum) / qr[my_idx]; besti = my_idx; }
+    } else {
+      for (int i = tid; i < V; i += ST) {
+        const float p = row[i];
+        if (p > 0.f) {
+          const float r = (p / psum) / qr[i];
+          if (r > bestp) { bestp = r; besti = i; }
+        }
       }
     }
   }
@@ -443,9 +525,14 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
     float c;
     if (conf_mode == DARK_CONF_NEG_ENTROPY) c = entropy;
     else if (conf_mode == DARK_CONF_MARGIN) c = a1 - a2;
-    else c = row[bi];
+    else c = list ? 0.f : row[bi];
     conf[m] = c;
     x0[m] = (int64_t)bi;
+    s->bin = bi;
+  }
+  if (list && conf_mode == DARK_CONF_PROB) {  // list mode: the probability of the winner lives in its owner thread
+    __syncthreads();
+    if (my_e > 0.f && my_idx == s->bin) conf[m] = my_p;
   }
 }
 
@@ -459,7 +546,7 @@ int launch_sample(const float* logits, int64_t ldl, int M, int V, float temperat
   DARK_CHECK_ARG(!(temperature > 0.f) || (noise && ldn >= V), "sample_rows: temperature > 0 needs noise [M,V]");
   DARK_CHECK_ARG(temperature >= 0.f, "sample_rows: negative temperature");
   static_assert(NRAD * 12 <= NLIN * 8, "the radix histograms alias the linear histogram");
-  const int smem = ((V + 3) & ~3) * 4 + NLIN * 8 + CAND_CAP * 4 + (int)sizeof(Scratch);
+  const int smem = ((V + 3) & ~3) * 4 + NLIN * 8 + CAND_CAP * 16 + (int)sizeof(Scratch);
   static int attr_smem = 0;
   if (smem > attr_smem) {
     DARK_CHECK_HIP(hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
