@@ -302,3 +302,69 @@ def test_skip_noop_steps_is_invisible(golden_meta):
     assert torch.equal(res[0][1], res[1][1]), "the device generator must end in the same state"
     changed = (res[0][0][1:] != res[0][0][:-1]).any(-1).any(-1)
     assert int(changed.sum()) <= 10  # only the 10 committing steps change x
+
+
+def test_full_size_properties_bf16(golden_meta):
+    """BASELINE config 2 at full size (512 deduction rows, 33 masks, 32 steps, bf16, T=0.1/top_p=0.9): the oracle
+    cannot run this in seconds, so check the size-independent invariants of the loop (generation_utils.py:488-540):
+    unmasked positions never change, the number of masks per row follows the k-schedule exactly, every committed id
+    is a valid vocabulary id, and the same seed gives the same trajectory twice (deterministic kernels)."""
+    m = _model(golden_meta["real"], False, torch.bfloat16)
+    ids = synth.make_inputs(512, "ded", seed=21).to(DEV)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(77)
+        out = m.diffusion_generate(inputs=ids, generation_config=_gc(45), return_dict_in_generate=True,
+                                   output_history=True, steps=32, temperature=0.1, alg="entropy", alg_temp=0,
+                                   top_p=0.9, skip_noop_steps=False)
+        runs.append(torch.stack(out.history))
+    hist = runs[0]
+    assert torch.equal(runs[0], runs[1]), "same seed, same inputs: trajectories must be identical"
+    x0 = torch.nn.functional.pad(ids, (0, 1), value=synth.MASK)
+    prev = x0
+    left = 33
+    for step, k in enumerate(O.transfer_schedule(33, 32)):
+        cur = hist[step]
+        was_mask = prev == synth.MASK
+        assert torch.equal(cur[~was_mask], prev[~was_mask]), f"step {step}: an unmasked position changed"
+        newly = was_mask & (cur != synth.MASK)
+        left -= k
+        # a committed id may itself be the MASK id (a legal vocabulary entry): such a row keeps one more mask
+        cnt = (cur == synth.MASK).sum(1)
+        assert bool(((cnt == left) | (cnt == left + 1)).all()), f"step {step}"
+        assert bool((newly.sum(1) <= k).all())
+        assert bool(((cur >= 0) & (cur < golden_meta["real"]["vocab_size"])).all())
+        prev = cur
+    assert int((hist[-1] == synth.MASK).sum()) <= 512 * 0.01
+
+
+def test_config4_shape_vs_oracle():
+    """BASELINE config 4 shape (N = 128, 12 heads of 64, long sequences) on a 2-layer cut: histories against the
+    oracle on the same noise, fp32."""
+    kw = dict(vocab_size=2048, hidden_size=768, intermediate_size=3072, num_hidden_layers=2, num_attention_heads=12,
+              num_key_value_heads=12, max_position_embeddings=128, mask_token_id=synth.MASK, pad_token_id=synth.END)
+    m = _model(kw, True)
+    cfg = O.OracleConfig(**{k: v for k, v in kw.items() if k in O.OracleConfig.__dataclass_fields__})
+    w = synth.make_weights(m.config, seed=0, rich=True)
+    g = torch.Generator().manual_seed(4)
+    B, n_in = 6, 127
+    ids = torch.randint(100, 2047, (B, n_in), generator=g)
+    ids[:, 0] = synth.BOS
+    ids[:, 40:103] = synth.MASK  # 63 masks + the padded one = 64 per row
+    noises = {}
+
+    def noise_fn(step, M, V):
+        if step not in noises:
+            noises[step] = torch.empty(M, V).exponential_(1, generator=g)
+        return noises[step]
+
+    gc = DreamGenerationConfig(mask_token_id=synth.MASK, pad_token_id=synth.END, max_length=128)
+    out = m.diffusion_generate(inputs=ids.to(DEV), generation_config=gc, return_dict_in_generate=True,
+                               output_history=True, steps=8, temperature=0.5, alg="entropy", alg_temp=0, top_p=0.9,
+                               _noise_fn=noise_fn)
+    _, hist = O.sample_loop(w, cfg, ids, max_length=128, steps=8, mask_token_id=synth.MASK, alg="entropy", alg_temp=0,
+                            temperature=0.5, top_p=0.9, noise_fn=lambda s, M, V: noises[s], tie_break="index")
+    got = torch.stack(out.history).cpu()
+    exp = torch.stack(hist)
+    mism = (got != exp).any(-1).any(-1)
+    assert not bool(mism.any()), f"history differs from the oracle at steps {mism.nonzero().view(-1).tolist()}"
