@@ -98,3 +98,43 @@ def make_inputs(batch: int, kind: str = "abd", nentity: int = FB15K237["nentity"
     else:
         raise ValueError(f"unknown layout kind: {kind}")
     return x
+
+
+def make_var_inputs(count: int, kind: str = "abd", n_masks: int = 8, nentity: int = FB15K237["nentity"],
+                    nrelation: int = FB15K237["nrelation"], seed: int = 1) -> List[torch.Tensor]:
+    """`count` un-padded int64 ``[1, L]`` inputs of the variable-length path (akgr/tokenizer.py:154-184):
+    abd ``[BOS, MASK x n_masks, SEP, observation, EOS]``, ded ``[BOS, query, SEP, MASK x n_masks, EOS]``."""
+    fixed = make_inputs(count, kind, nentity, nrelation, seed)  # supplies the unmasked side
+    out = []
+    for b in range(count):
+        row = fixed[b]
+        if kind == "abd":
+            obs = row[2 + QRY_LEN:2 + QRY_LEN + ANS_LEN]
+            obs = obs[obs != END]
+            ids = [BOS] + [MASK] * n_masks + [SEP] + obs.tolist() + [END]
+        elif kind == "ded":
+            qry = row[1:1 + QRY_LEN]
+            qry = qry[qry != END]
+            ids = [BOS] + qry.tolist() + [SEP] + [MASK] * n_masks + [END]
+        else:
+            raise ValueError(f"unknown layout kind: {kind}")
+        out.append(torch.tensor([ids], dtype=torch.long))
+    return out
+
+
+def boost_edit_tokens(weights: Dict[str, torch.Tensor], expand_gain: float = 0.0, delete_gain: float = 0.0,
+                      mask_id: int = MASK, expand_id: int = EXPAND, delete_id: int = END) -> Dict[str, torch.Tensor]:
+    """A random-init model almost never emits EXPAND / DELETE.  Point their lm_head rows along the MASK
+    embedding (the residual stream of a masked position keeps a large component of it) so that synthetic
+    runs exercise the edit branches; gains are in units of the typical row norm."""
+    w = dict(weights)
+    head = w["lm_head.weight"].clone()
+    e = w["model.embed_tokens.weight"][mask_id]
+    unit = e / e.norm()
+    typical = head.norm(dim=1).median()
+    if expand_gain:
+        head[expand_id] = unit * typical * expand_gain
+    if delete_gain:
+        head[delete_id] = unit * typical * delete_gain
+    w["lm_head.weight"] = head
+    return w

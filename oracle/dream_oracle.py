@@ -15,6 +15,8 @@ reference lines it follows (paths relative to ``/root/reference/``):
 * ``akgr/abduction_model/model/custom_mydream/generation_utils.py``
   (top_p_logits :37-48, top_k_logits :50-55, sample_tokens :58-90,
   _sample :435-548)
+* ``akgr/abduction_model/model/custom_mydream/generation_expand_utils.py``
+  (variable-length EXPAND/DELETE sampler: diffusion_generate :294-356, _sample :358-503)
 
 Pinning: the reference has no tests or golden vectors of its own.
 The oracle is pinned by fixtures generated from the reference's own code,
@@ -317,6 +319,114 @@ def sample_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
         x = tokens_hook(i, x, logits)
         history.append(x.clone())
     return x, history
+
+
+# --------------------------------------------------------------------------- variable-length loop
+def expand_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: int, mask_token_id: int,
+                eos_token_id: int, delete_token_id: int, expand_token_id: int,
+                expand_budget: Optional[int] = None, pad_delete_to_right: bool = False,
+                number_transfer_tokens: int = 1, alg: str = "entropy", alg_temp: Optional[float] = None,
+                temperature: float = 0.0, top_p: Optional[float] = None, top_k: Optional[int] = None,
+                noise_fn: Optional[Callable[[int, int, int], torch.Tensor]] = None,
+                forward_fn: Optional[Callable] = None, tie_break: str = "torch",
+                trace: Optional[SampleTrace] = None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """``generation_expand_utils.py:294-356`` (prefix / mask bookkeeping) + ``_sample`` ``:358-503``: the
+    DreamOn-style variable-length sampler.  ``input_ids`` is ``[1, L]`` (the path inspects row 0 only, :445-495).
+    Returns (x ``[1, max_length]``, history) where history holds the up to three snapshots per step the reference
+    appends (after the commit :444-445, after deletions :474-476, after expansions :493-495).
+
+    ``noise_fn(step, M, V)`` injects the Exp(1) draws of the categorical sample; ``tie_break`` as in sample_loop.
+    """
+    assert input_ids.dim() == 2 and input_ids.shape[0] == 1
+    mask_pos = torch.where(input_ids == mask_token_id)[1]
+    if mask_pos.numel() == 0:
+        raise ValueError("No mask tokens found in the input_ids.")                          # :318-319
+    start_gen_len = int(mask_pos.numel())
+    prefix_len = int(mask_pos[0])
+    if input_ids.shape[1] > max_length:                                                        # :177-183
+        raise ValueError(f"Input length of input_ids is {input_ids.shape[1]}, but `max_length` is set to {max_length}.")
+    num_generation_tokens = start_gen_len
+    max_gen_len = max_length - prefix_len
+    if expand_budget is None:
+        expand_budget = max_gen_len * 2
+    fwd = forward_fn or (lambda xx, m, p: forward_logits(w, cfg, xx, m, p))
+    history: List[torch.Tensor] = []
+    L_in = input_ids.shape[1]
+
+    x = F.pad(input_ids, (0, max_length - L_in), value=eos_token_id)
+    for i in range(2 * max_gen_len + 2 * expand_budget):
+        cwl = L_in - start_gen_len + num_generation_tokens
+        am = torch.ones(1, cwl, dtype=torch.int16)
+        am = F.pad(am, (0, max_length - cwl), value=0)          # negative pad crops, as in the reference (:401)
+        mask_index = (x == mask_token_id) & (am == 1)
+        if torch.all(~mask_index[:, :cwl]):
+            break
+        tok_idx = am.long().cumsum(-1) - 1
+        tok_idx.masked_fill_(am == 0, 1)
+        attn4d = torch.logical_and(am.unsqueeze(1).unsqueeze(-2), am.unsqueeze(1).unsqueeze(-1))
+        logits = fwd(x, attn4d, tok_idx)
+        logits = torch.cat([logits[:, :1], logits[:, :-1]], dim=1)
+        logits = logits[mask_index]
+        if cwl == max_length or expand_budget == 0:              # :421-422
+            logits[:, expand_token_id] -= 1e9
+        nz = noise_fn(i, logits.shape[0], logits.shape[1]) if (noise_fn and temperature > 0) else None
+        if alg == "maskgit_plus":
+            confidence, x0 = sample_tokens(logits, temperature=temperature, top_p=top_p, top_k=top_k, noise=nz)
+        elif alg == "topk_margin":
+            confidence, x0 = sample_tokens(logits, temperature=temperature, top_p=top_p, top_k=top_k,
+                                           margin_confidence=True, noise=nz)
+        elif alg == "entropy":
+            confidence, x0 = sample_tokens(logits, temperature=temperature, top_p=top_p, top_k=top_k,
+                                           neg_entropy=True, noise=nz)
+        else:
+            raise RuntimeError(f"Unknown alg: {alg}")
+        if trace is not None:
+            trace.k.append(number_transfer_tokens)
+            trace.confidence.append(confidence.clone())
+            trace.x0.append(x0.clone())
+        if alg_temp is None or alg_temp == 0:
+            if tie_break == "index":
+                if number_transfer_tokens > confidence.numel():
+                    raise RuntimeError("selected index k out of range")
+                transfer_index = torch.sort(confidence, descending=True, stable=True).indices[:number_transfer_tokens]
+            else:
+                _, transfer_index = torch.topk(confidence, number_transfer_tokens)
+        else:
+            confidence = F.softmax(confidence / alg_temp, dim=-1)
+            transfer_index = torch.multinomial(confidence, num_samples=number_transfer_tokens)
+        x0_ = torch.zeros_like(x0, dtype=torch.long) + mask_token_id
+        x0_[transfer_index] = x0[transfer_index].clone()
+        x[mask_index] = x0_
+        history.append(x[0, :cwl].clone())
+
+        # ---- delete (:447-476)
+        if pad_delete_to_right:
+            row = x[0]
+            hits = (row == delete_token_id).nonzero(as_tuple=True)[0]
+            if hits.numel() > 0:
+                first = int(hits[0])
+                fill = (torch.arange(row.size(0)) >= first) & mask_index[0]
+                row.masked_fill_(fill, delete_token_id)
+                x = row.unsqueeze(0)
+        del_idx = ((x[0] == delete_token_id) & mask_index[0]).nonzero(as_tuple=False).squeeze(1)
+        if del_idx.numel() > 0:
+            for idx in sorted(del_idx.tolist(), reverse=True):
+                x = torch.cat((x[:, :idx], x[:, idx + 1:], torch.tensor([[mask_token_id]])), dim=1)
+                num_generation_tokens -= 1
+            cwl = L_in - start_gen_len + num_generation_tokens
+            history.append(x[0, :cwl].clone())
+        # ---- expand (:477-495)
+        exp_idx = (x[0] == expand_token_id).nonzero(as_tuple=False).squeeze(1)
+        if exp_idx.numel() > 0:
+            for idx in sorted(exp_idx.tolist(), reverse=True):
+                x = torch.cat((x[:, :idx], torch.tensor([[mask_token_id, mask_token_id]]), x[:, idx + 1:]), dim=1)
+                num_generation_tokens += 1
+                expand_budget -= 1
+                if x.shape[1] > max_length:
+                    x = x[:, :max_length]
+            cwl = L_in - start_gen_len + num_generation_tokens
+            history.append(x[0, :cwl].clone())
+    return x[:, :max_length], history
 
 
 # --------------------------------------------------------------------------- helpers shared by tests / bench

@@ -25,3 +25,14 @@ def goldens():
 def golden_meta():
     with open(os.path.join(GOLDEN_DIR, "reference_goldens.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def goldens_expand():
+    return np.load(os.path.join(GOLDEN_DIR, "reference_goldens_expand.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_expand_meta():
+    with open(os.path.join(GOLDEN_DIR, "reference_goldens_expand.json")) as f:
+        return json.load(f)

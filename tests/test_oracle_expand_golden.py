@@ -1,0 +1,62 @@
+"""Pins the oracle's variable-length EXPAND/DELETE loop (oracle.dream_oracle.expand_loop) against
+fixtures generated from the reference's own `DreamModel.diffusion_generate`
+(tests/golden/make_goldens_expand.py): the final sequence and every history snapshot must be identical."""
+import numpy as np
+import pytest
+import torch
+
+from dark_amd import synth
+from oracle import dream_oracle as O
+
+
+@pytest.fixture(scope="module")
+def mini(golden_expand_meta, goldens_expand):
+    kw = golden_expand_meta["mini"]
+    cfg = O.OracleConfig(**{k: v for k, v in kw.items() if k in O.OracleConfig.__dataclass_fields__})
+    w = synth.boost_edit_tokens(synth.make_weights(cfg, seed=0, rich=True), **golden_expand_meta["boost"])
+    chk = np.array([float(w[k].double().sum()) for k in sorted(w)])
+    np.testing.assert_allclose(chk, goldens_expand["w_checksum"], rtol=0, atol=0)
+    return cfg, w
+
+
+def split_history(g, name):
+    lens = g[name + "_hist_len"]
+    flat = g[name + "_hist"]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    return [flat[offs[i]:offs[i + 1]] for i in range(len(lens))]
+
+
+def run_case(cfg, w, g, c, **over):
+    kw = dict(c["kw"])
+    ids = torch.from_numpy(g["in_" + c["input"]]).clone()
+    torch.manual_seed(c["seed"])
+    return O.expand_loop(w, cfg, ids, max_length=c["max_length"], mask_token_id=synth.MASK,
+                         eos_token_id=synth.END, delete_token_id=synth.END, expand_token_id=synth.EXPAND,
+                         expand_budget=kw.get("expand_budget"), pad_delete_to_right=kw.get("pad_delete_to_right", False),
+                         number_transfer_tokens=kw["number_transfer_tokens"], alg=kw["alg"], alg_temp=kw["alg_temp"],
+                         temperature=kw["temperature"], top_p=kw.get("top_p"), top_k=kw.get("top_k"), **over)
+
+
+def test_expand_loop_matches_reference(mini, goldens_expand, golden_expand_meta):
+    cfg, w = mini
+    for c in golden_expand_meta["cases"]:
+        x, hist = run_case(cfg, w, goldens_expand, c)
+        want = split_history(goldens_expand, c["name"])
+        assert len(hist) == len(want), c["name"]
+        for i, (a, b) in enumerate(zip(hist, want)):
+            assert np.array_equal(a.numpy(), b), f"{c['name']} snapshot {i}"
+        assert np.array_equal(x.numpy(), goldens_expand[c["name"] + "_seq"]), c["name"]
+
+
+def test_goldens_cover_the_edit_branches(golden_expand_meta):
+    cases = golden_expand_meta["cases"]
+    assert sum(c["shrinks"] for c in cases) >= 10 and sum(c["grows"] for c in cases) >= 10
+    assert any(c["kw"].get("pad_delete_to_right") for c in cases)
+    assert any(c["kw"].get("expand_budget") == 0 for c in cases)
+
+
+def test_no_mask_raises(mini):
+    cfg, w = mini
+    with pytest.raises(ValueError, match="No mask tokens"):
+        O.expand_loop(w, cfg, torch.tensor([[0, 101, 4, 102, 2]]), max_length=10, mask_token_id=synth.MASK,
+                      eos_token_id=synth.END, delete_token_id=synth.END, expand_token_id=synth.EXPAND)
