@@ -11,14 +11,16 @@ import types
 from .configuration_dream import DreamConfig
 from .generation_utils import DreamGenerationConfig, DreamGenerationMixin, DreamModelOutput
 from .modeling_dream_length import DreamModel_length
+from .modeling_dream import DreamModel
 
 __all__ = ["DreamConfig", "DreamGenerationConfig", "DreamGenerationMixin", "DreamModelOutput",
-           "DreamModel_length", "install_akgr_alias"]
+           "DreamModel_length", "DreamModel", "install_akgr_alias"]
 
 
 def install_akgr_alias() -> None:
     """Expose this package as akgr.abduction_model.model.custom_mydream."""
-    from . import configuration_dream, generation_utils, modeling_dream_length
+    from . import (configuration_dream, generation_expand_utils, generation_utils, modeling_dream,
+                   modeling_dream_length)
     chain = ["akgr", "akgr.abduction_model", "akgr.abduction_model.model",
              "akgr.abduction_model.model.custom_mydream"]
     for name in chain:
@@ -28,6 +30,7 @@ def install_akgr_alias() -> None:
             sys.modules[name] = m
     base = chain[-1]
     for sub, mod in (("configuration_dream", configuration_dream), ("generation_utils", generation_utils),
-                     ("modeling_dream_length", modeling_dream_length)):
+                     ("modeling_dream_length", modeling_dream_length),
+                     ("generation_expand_utils", generation_expand_utils), ("modeling_dream", modeling_dream)):
         sys.modules[f"{base}.{sub}"] = mod
         setattr(sys.modules[base], sub, mod)

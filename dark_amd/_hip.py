@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libdark_hip.so")
 DARK_OK = 0
 DARK_F32, DARK_BF16 = 0, 1
 CONF_PROB, CONF_MARGIN, CONF_NEG_ENTROPY = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class LayerWeights(C.Structure):
@@ -56,6 +56,14 @@ SIGNATURES = {
     "dark_denoise_step": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dark_expand_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "dark_expand_block_logit": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dark_expand_commit_edit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                          C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dark_prof_select_gemm": (C.c_int, [C.c_int]),
     "dark_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dark_dbg_gemm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

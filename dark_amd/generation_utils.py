@@ -169,6 +169,17 @@ class DreamGenerationMixin:
                            generation_config: Optional[DreamGenerationConfig] = None,
                            **kwargs) -> Union[DreamModelOutput, torch.LongTensor]:
         """generation_utils.py:300-365."""
+        return self._generate_fixed(inputs, generation_config, **kwargs)
+
+    def _sample(self, *args, **kwargs):
+        """generation_utils.py:435-548."""
+        return self._sample_fixed(*args, **kwargs)
+
+    @torch.no_grad()
+    def _generate_fixed(self, inputs: Optional[torch.Tensor] = None,
+                        generation_config: Optional[DreamGenerationConfig] = None,
+                        **kwargs) -> Union[DreamModelOutput, torch.LongTensor]:
+        """The fixed-length entry (generation_utils.py:300-365; also generation_expand_utils.py:505-570)."""
         generation_config = self._prepare_generation_config(generation_config, **kwargs)
         tokens_hook = kwargs.pop("generation_tokens_hook_func", None)
         logits_hook = kwargs.pop("generation_logits_hook_func", None)
@@ -210,16 +221,16 @@ class DreamGenerationMixin:
 
         input_ids, attention_mask = self._expand_inputs_for_generation(
             expand_size=generation_config.num_return_sequences, input_ids=input_ids, attention_mask=attention_mask)
-        return self._sample(input_ids, attention_mask=attention_mask, generation_config=generation_config,
-                            generation_tokens_hook_func=tokens_hook, generation_logits_hook_func=logits_hook,
-                            noise_fn=noise_fn, trace=trace)
+        return self._sample_fixed(input_ids, attention_mask=attention_mask, generation_config=generation_config,
+                                  generation_tokens_hook_func=tokens_hook, generation_logits_hook_func=logits_hook,
+                                  noise_fn=noise_fn, trace=trace)
 
     # ------------------------------------------------------------------ the loop
-    def _sample(self, input_ids: torch.LongTensor, attention_mask: Optional[torch.Tensor],
-                generation_config: DreamGenerationConfig, generation_tokens_hook_func=None,
-                generation_logits_hook_func=None, noise_fn: Optional[Callable] = None,
-                trace: Optional[dict] = None) -> Union[DreamModelOutput, torch.LongTensor]:
-        """generation_utils.py:435-548."""
+    def _sample_fixed(self, input_ids: torch.LongTensor, attention_mask: Optional[torch.Tensor],
+                      generation_config: DreamGenerationConfig, generation_tokens_hook_func=None,
+                      generation_logits_hook_func=None, noise_fn: Optional[Callable] = None,
+                      trace: Optional[dict] = None) -> Union[DreamModelOutput, torch.LongTensor]:
+        """generation_utils.py:435-548 (and its copy generation_expand_utils.py:572-672)."""
         gc = generation_config
         steps, eps, alg, alg_temp = gc.steps, gc.eps, gc.alg, gc.alg_temp
         temperature, top_p, top_k = gc.temperature, gc.top_p, gc.top_k

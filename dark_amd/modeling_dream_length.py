@@ -255,6 +255,7 @@ class _Base(nn.Module):
 class DreamModel_length(DreamGenerationMixin, nn.Module):
     """modeling_dream_length.py:736-824 (inference surface)."""
     config_class = DreamConfig
+    generation_config_class = DreamGenerationConfig
 
     def __init__(self, config: DreamConfig):
         super().__init__()
@@ -262,7 +263,7 @@ class DreamModel_length(DreamGenerationMixin, nn.Module):
         self.vocab_size = config.vocab_size
         self.model = _Base(config)
         self.lm_head = _Linear(config.hidden_size, config.vocab_size, False)
-        self.generation_config = DreamGenerationConfig.from_model_config(config)
+        self.generation_config = self.generation_config_class.from_model_config(config)
         self._packed: Optional[PackedWeights] = None
         self._packed_key = None
         self._states: Dict[Tuple[int, int], HipState] = {}
@@ -320,7 +321,7 @@ class DreamModel_length(DreamGenerationMixin, nn.Module):
         if torch_dtype is not None:
             model.to(torch_dtype)
         if os.path.exists(os.path.join(path, "generation_config.json")):
-            model.generation_config = DreamGenerationConfig.from_pretrained(path)
+            model.generation_config = cls.generation_config_class.from_pretrained(path)
         return model
 
     def save_pretrained(self, path: str) -> None:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DARK_HIP_ABI_VERSION 1
+#define DARK_HIP_ABI_VERSION 2
 
 #define DARK_OK 0
 #define DARK_ERR_ARG 1         /* bad shape / pointer / unsupported size */
@@ -140,6 +140,41 @@ int dark_denoise_step(const dark_model_desc* m, int64_t* x, const int32_t* pos, 
                       int B, int N, int M, int64_t mask_id, float temperature, float top_p, int top_k,
                       int conf_mode, const float* noise, int k, void* workspace, size_t workspace_bytes,
                       void* stream);
+
+/* ---- variable-length (EXPAND / DELETE) sampler, batched.
+ * Replaces the per-step tensor ops of DreamGenerationMixin._sample in
+ * akgr/abduction_model/model/custom_mydream/generation_expand_utils.py:358-503.  The reference runs ONE sequence
+ * per call (it edits `x[0]` only); here every sequence b of a [B,N] batch (N = max_length, rows padded with eos)
+ * carries its own state, so B independent reference runs advance per launch:
+ *   win[b]    int32 current_window_length (:397), IN/OUT of the edit step
+ *   budget[b] int32 remaining expand_budget (:381-383, :488)
+ *   limit[b]  int32 number of loop iterations the reference would allow (2*max_gen_len + 2*expand_budget, :395)
+ *
+ * dark_expand_prepare: window mask and tok_idx (:398-412) as key_mask/pos for dark_forward_hidden, the masked-row
+ * lists of `logits[mask_index]` with the logit shift (:403, :417-418) for dark_lm_head_rows, and the exit test
+ * (:404-405): active[b] = 1 iff step < limit[b] and the window still holds a mask; count[0] = masked rows M over
+ * the active sequences, count[1] = active sequences.  key_mask/pos/row_index/src_rows hold B*N entries. */
+int dark_expand_prepare(const int64_t* x, const int32_t* win, const int32_t* limit, int step, int B, int N,
+                        int64_t mask_id, uint8_t* key_mask, int32_t* pos, int32_t* row_index, int32_t* src_rows,
+                        uint8_t* active, int32_t* count, void* stream);
+
+/* `logits[:, expand_token_id] -= 1e9` for the rows of sequences whose window is full or whose budget is spent
+ * (:420-422).  logits [M, ldl] fp32 IN/OUT, row_index [M] from dark_expand_prepare. */
+int dark_expand_block_logit(float* logits, int64_t ldl, int V, const int32_t* row_index, int M, int B, int N,
+                            const int32_t* win, const int32_t* budget, int64_t expand_id, void* stream);
+
+/* Per active sequence: `torch.topk(confidence, k)` over its masked positions (ties -> lower index; k is clamped
+ * to their number, where the reference raises) and commit of x0 there (:434-442); pad_delete_to_right (:449-462);
+ * removal of this step's DELETE tokens with MASK appended at the row end (:465-473); replacement of every
+ * EXPAND token in the row by two MASKs, truncated to N (:478-491); win/budget updated (:473, :487-488).
+ *   conf/x0 [M] from dark_sample_rows;  delete_id / expand_id: -1 = none
+ *   snaps [3,B,N] int64 + snap_len [3,B] int32, or both NULL: the rows the reference appends to `histories`
+ *   after the commit (:444-445), after deletions (:474-476), after expansions (:493-495); snap_len = visible
+ *   length, -1 where the reference appends nothing. */
+int dark_expand_commit_edit(int64_t* x, int B, int N, const int32_t* row_index, int M, const float* conf,
+                            const int64_t* x0, int k, const uint8_t* active, int32_t* win, int32_t* budget,
+                            int64_t mask_id, int64_t delete_id, int64_t expand_id, int pad_delete_to_right,
+                            int64_t* snaps, int32_t* snap_len, void* stream);
 
 /* ---- measurement hook (no counterpart in the reference): bracket every launch of ONE GEMM flavour
  * (epi as in dark_dbg_gemm; -1 = off) with HIP events on the launch stream.  dark_prof_read waits for

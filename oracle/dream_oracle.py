@@ -230,6 +230,8 @@ class SampleTrace:
     confidence: List[torch.Tensor] = field(default_factory=list)
     x0: List[torch.Tensor] = field(default_factory=list)
     mask_logits: List[torch.Tensor] = field(default_factory=list)
+    states: List[tuple] = field(default_factory=list)   # expand_loop: (x, window, expand_budget) entering a step
+    snaps: List[List[torch.Tensor]] = field(default_factory=list)  # expand_loop: the step's history snapshots
 
 
 def sample_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: int, steps: int,
@@ -384,49 +386,69 @@ def expand_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
             trace.k.append(number_transfer_tokens)
             trace.confidence.append(confidence.clone())
             trace.x0.append(x0.clone())
-        if alg_temp is None or alg_temp == 0:
-            if tie_break == "index":
-                if number_transfer_tokens > confidence.numel():
-                    raise RuntimeError("selected index k out of range")
-                transfer_index = torch.sort(confidence, descending=True, stable=True).indices[:number_transfer_tokens]
-            else:
-                _, transfer_index = torch.topk(confidence, number_transfer_tokens)
-        else:
-            confidence = F.softmax(confidence / alg_temp, dim=-1)
-            transfer_index = torch.multinomial(confidence, num_samples=number_transfer_tokens)
-        x0_ = torch.zeros_like(x0, dtype=torch.long) + mask_token_id
-        x0_[transfer_index] = x0[transfer_index].clone()
-        x[mask_index] = x0_
-        history.append(x[0, :cwl].clone())
-
-        # ---- delete (:447-476)
-        if pad_delete_to_right:
-            row = x[0]
-            hits = (row == delete_token_id).nonzero(as_tuple=True)[0]
-            if hits.numel() > 0:
-                first = int(hits[0])
-                fill = (torch.arange(row.size(0)) >= first) & mask_index[0]
-                row.masked_fill_(fill, delete_token_id)
-                x = row.unsqueeze(0)
-        del_idx = ((x[0] == delete_token_id) & mask_index[0]).nonzero(as_tuple=False).squeeze(1)
-        if del_idx.numel() > 0:
-            for idx in sorted(del_idx.tolist(), reverse=True):
-                x = torch.cat((x[:, :idx], x[:, idx + 1:], torch.tensor([[mask_token_id]])), dim=1)
-                num_generation_tokens -= 1
-            cwl = L_in - start_gen_len + num_generation_tokens
-            history.append(x[0, :cwl].clone())
-        # ---- expand (:477-495)
-        exp_idx = (x[0] == expand_token_id).nonzero(as_tuple=False).squeeze(1)
-        if exp_idx.numel() > 0:
-            for idx in sorted(exp_idx.tolist(), reverse=True):
-                x = torch.cat((x[:, :idx], torch.tensor([[mask_token_id, mask_token_id]]), x[:, idx + 1:]), dim=1)
-                num_generation_tokens += 1
-                expand_budget -= 1
-                if x.shape[1] > max_length:
-                    x = x[:, :max_length]
-            cwl = L_in - start_gen_len + num_generation_tokens
-            history.append(x[0, :cwl].clone())
+            trace.states.append((x.clone(), cwl, expand_budget))
+        x, d_gen, n_exp, snaps = expand_commit_edit(
+            x, mask_index, confidence, x0, number_transfer_tokens=number_transfer_tokens, alg_temp=alg_temp,
+            tie_break=tie_break, mask_token_id=mask_token_id, delete_token_id=delete_token_id,
+            expand_token_id=expand_token_id, pad_delete_to_right=pad_delete_to_right, max_length=max_length,
+            window=cwl)
+        num_generation_tokens += d_gen
+        expand_budget -= n_exp
+        history.extend(snaps)
+        if trace is not None:
+            trace.snaps.append(snaps)
     return x[:, :max_length], history
+
+
+def expand_commit_edit(x, mask_index, confidence, x0, *, number_transfer_tokens: int, alg_temp, tie_break: str,
+                       mask_token_id: int, delete_token_id: int, expand_token_id: int, pad_delete_to_right: bool,
+                       max_length: int, window: int):
+    """One iteration's commit and sequence edits, generation_expand_utils.py:434-495, on `x` [1, max_length].
+    Returns (x, change of num_generation_tokens, number of expansions, history snapshots)."""
+    snaps: List[torch.Tensor] = []
+    if alg_temp is None or alg_temp == 0:
+        if tie_break == "index":
+            if number_transfer_tokens > confidence.numel():
+                raise RuntimeError("selected index k out of range")
+            transfer_index = torch.sort(confidence, descending=True, stable=True).indices[:number_transfer_tokens]
+        else:
+            _, transfer_index = torch.topk(confidence, number_transfer_tokens)
+    else:
+        confidence = F.softmax(confidence / alg_temp, dim=-1)
+        transfer_index = torch.multinomial(confidence, num_samples=number_transfer_tokens)
+    x0_ = torch.zeros_like(x0, dtype=torch.long) + mask_token_id
+    x0_[transfer_index] = x0[transfer_index].clone()
+    x[mask_index] = x0_
+    snaps.append(x[0, :window].clone())
+    d_gen = 0
+
+    # ---- delete (:447-476)
+    if pad_delete_to_right:
+        row = x[0]
+        hits = (row == delete_token_id).nonzero(as_tuple=True)[0]
+        if hits.numel() > 0:
+            first = int(hits[0])
+            fill = (torch.arange(row.size(0)) >= first) & mask_index[0]
+            row.masked_fill_(fill, delete_token_id)
+            x = row.unsqueeze(0)
+    del_idx = ((x[0] == delete_token_id) & mask_index[0]).nonzero(as_tuple=False).squeeze(1)
+    if del_idx.numel() > 0:
+        for idx in sorted(del_idx.tolist(), reverse=True):
+            x = torch.cat((x[:, :idx], x[:, idx + 1:], torch.tensor([[mask_token_id]])), dim=1)
+            d_gen -= 1
+        snaps.append(x[0, :max(window + d_gen, 0)].clone())
+    # ---- expand (:477-495)
+    n_exp = 0
+    exp_idx = (x[0] == expand_token_id).nonzero(as_tuple=False).squeeze(1)
+    if exp_idx.numel() > 0:
+        for idx in sorted(exp_idx.tolist(), reverse=True):
+            x = torch.cat((x[:, :idx], torch.tensor([[mask_token_id, mask_token_id]]), x[:, idx + 1:]), dim=1)
+            d_gen += 1
+            n_exp += 1
+            if x.shape[1] > max_length:
+                x = x[:, :max_length]
+        snaps.append(x[0, :max(window + d_gen, 0)].clone())
+    return x, d_gen, n_exp, snaps
 
 
 # --------------------------------------------------------------------------- helpers shared by tests / bench
