@@ -161,19 +161,23 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
         if mask_id is None:
             raise ValueError("mask_token_id must be set in the generation config")
 
-        # ---- per-row bookkeeping of :313-334 (host integers; the prompts are tiny)
-        host_rows = [r.detach().to("cpu", torch.int64) for r in rows]
-        lengths, n_masks, prefixes = [], [], []
-        for r in host_rows:
-            where = (r[0] == mask_id).nonzero(as_tuple=False).flatten()
-            if where.numel() == 0:
-                raise ValueError("No mask tokens found in the input_ids.")                       # :318-319
-            lengths.append(int(r.shape[1]))
-            n_masks.append(int(where.numel()))
-            prefixes.append(int(where[0]))
+        # ---- per-row bookkeeping of :313-334, vectorised on the host (one device->host copy for the whole batch)
+        lengths = [int(r.shape[1]) for r in rows]
+        flat = torch.cat([r.detach().reshape(-1) for r in rows]).to("cpu", torch.int64)
+        lens_t = torch.tensor(lengths, dtype=torch.int64)
+        row_of = torch.repeat_interleave(torch.arange(len(rows)), lens_t)
+        col_of = torch.arange(flat.numel()) - torch.repeat_interleave(torch.cumsum(lens_t, 0) - lens_t, lens_t)
+        is_mask = flat == mask_id
+        n_masks_t = torch.bincount(row_of[is_mask], minlength=len(rows))
+        if bool((n_masks_t == 0).any()):
+            raise ValueError("No mask tokens found in the input_ids.")                           # :318-319
+        first = torch.full((len(rows),), 1 << 30, dtype=torch.int64)
+        first.scatter_reduce_(0, row_of[is_mask], col_of[is_mask], reduce="amin")
+        n_masks, prefixes = n_masks_t.tolist(), first.tolist()
+        packed = (flat, row_of, col_of, lengths)
         has_default_max_length = kwargs.get("max_length") is None and gc.max_length is not None
         max_lengths = set()
-        for L, nm in zip(lengths, n_masks):
+        for L, nm in set(zip(lengths, n_masks)):
             g = self._prepare_generated_length(_copy_lengths(gc), has_default_max_length, L, nm)
             self._validate_generated_length(g, L, has_default_max_length)
             max_lengths.add(int(g.max_length))
@@ -187,7 +191,7 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
                 f" than your model's device. `input_ids` is on {rows[0].device.type}, whereas the model"
                 f" is on {self.device.type}. You may experience unexpected behaviors or slower generation.",
                 UserWarning)
-        return self._sample(host_rows, prefixes, n_masks, gc, _single=single, _noise_fn=noise_fn, _trace=trace,
+        return self._sample(packed, prefixes, n_masks, gc, _single=single, _noise_fn=noise_fn, _trace=trace,
                             _compact=compact)
 
     # ------------------------------------------------------------------ the loop
@@ -196,10 +200,13 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
         """generation_expand_utils.py:358-503 for every row at once.  `input_ids`: a `[1, L]` tensor with scalar
         `prefix_len` / `start_gen_len` (the reference signature) or lists of them."""
         gc = generation_config
-        if isinstance(input_ids, torch.Tensor):
-            input_ids, prefix_len, start_gen_len = [input_ids.detach().to("cpu", torch.int64)], [int(prefix_len)], \
-                [int(start_gen_len)]
+        if isinstance(input_ids, torch.Tensor):   # the reference signature: one [1, L] prompt
+            L = int(input_ids.shape[1])
+            input_ids = (input_ids.detach().reshape(-1).to("cpu", torch.int64), torch.zeros(L, dtype=torch.int64),
+                         torch.arange(L), [L])
+            prefix_len, start_gen_len = [int(prefix_len)], [int(start_gen_len)]
             _single = True if _single is None else _single
+        flat, row_of, col_of, lengths = input_ids
         device = self.device
         if device.type != "cuda":
             raise RuntimeError("dark_amd runs on a HIP device only: move the model with .to('cuda')")
@@ -221,7 +228,7 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
         if expand_id is None:
             raise ValueError("expand_token_id must be set in the generation config")
         stochastic_rank = not (alg_temp is None or alg_temp == 0)
-        B0, V = len(input_ids), self.config.vocab_size
+        B0, V = len(lengths), self.config.vocab_size
         if stochastic_rank and B0 > 1:
             raise NotImplementedError("alg_temp > 0 (multinomial ranking, :436-439) is implemented for one sequence "
                                       "per call only")
@@ -229,14 +236,13 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
 
         # ---- per-row state (:378-395)
         x_host = torch.full((B0, N), int(eos_id), dtype=torch.int64)
-        for b, r in enumerate(input_ids):
-            x_host[b, :r.shape[1]] = r[0]
+        x_host[row_of, col_of] = flat
         max_gen = [N - p for p in prefix_len]
         budget0 = [(2 * g if gc.expand_budget is None else int(gc.expand_budget)) for g in max_gen]
         limit0 = [2 * g + 2 * e for g, e in zip(max_gen, budget0)]
         i32 = dict(dtype=torch.int32, device=device)
         x = x_host.to(device)
-        win = torch.tensor([r.shape[1] for r in input_ids], **i32)   # L - start_gen_len + num_generation_tokens
+        win = torch.tensor(lengths, **i32)   # L - start_gen_len + num_generation_tokens
         budget = torch.tensor(budget0, **i32)
         limit = torch.tensor(limit0, **i32)
         origin = torch.arange(B0, device=device)        # row of the caller's batch each live row belongs to
