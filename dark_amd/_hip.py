@@ -64,6 +64,16 @@ SIGNATURES = {
     "dark_expand_commit_edit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                           C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dark_logprob_workspace_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.c_int]),
+    "dark_lm_head_logprob": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "dark_logprob_from_logits": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p]),
+    "dark_grpo_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dark_shift_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dark_grpo_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p]),
     "dark_prof_select_gemm": (C.c_int, [C.c_int]),
     "dark_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dark_dbg_gemm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

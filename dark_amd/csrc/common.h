@@ -97,13 +97,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // ---- launchers implemented across the .hip files --------------------------
 // GEMM epilogues: C[M,N] = A[M,K] * W[N,K]^T (+...)
-enum Epi { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_F32 = 3 };
+enum Epi { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_F32 = 3, EPI_LSE = 4 };
 
 // A: [M,K] dtype, W: [Npad,K] dtype (rows padded to a multiple of 128 with zeros).
 // EPI_BIAS  : out (dtype) [M,ldo] = acc + bias[n]
 // EPI_RESID : resid (fp32) [M,ldo] += acc
 // EPI_SWIGLU: W rows interleaved in groups of 32 (gate|up); out (dtype) [M,ldo], ldo cols = N/2
 // EPI_F32   : out (fp32) [M,ldo] = acc, columns n < N only
+// EPI_LSE   : bf16 only; bias = int64 targets [M]; out = float2 part[M][ldo] (max, sum exp(acc - max)) per
+//             64-column wave slice, ldo = 2*ceil(N/128), followed by float tgt[M] = acc[m][target[m]]
 int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out,
                 int M, int N, int K, int64_t ldo, hipStream_t st);
 

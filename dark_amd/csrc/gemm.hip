@@ -255,6 +255,41 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
         }
         store_pair_bf16(v[0], v[1], (bf16_t*)out + mrow * ldo, n0 + wn * WN + np * 32, row_ok ? N : 0, fq, vec_ok);
       }
+    } else if constexpr (EPI == EPI_LSE) {
+      // log-sum-exp partial of this wave's WN columns for row m: the 16 columns of an MFMA tile sit in the four
+      // lanes frow, frow+16, frow+32, frow+48 (4 registers each).  out = float2 part[M][ldo] then float tgt[M];
+      // `bias` carries the int64 target ids.
+      const int cb = n0 + wn * WN + 4 * fq;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int ni = 0; ni < TNW; ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cb + ni * 16 + e < N) mx = fmaxf(mx, acc[ni][mi][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < TNW; ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cb + ni * 16 + e < N) sum += __builtin_amdgcn_exp2f((acc[ni][mi][e] - mx) * 1.44269504088896341f);
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      if (row_ok) {
+        if (fq == 0) ((float2*)out)[mrow * ldo + tn * 2 + wn] = make_float2(mx, sum);
+        const int64_t t = ((const int64_t*)bias)[mrow];
+        const int tc = (int)(t < 0 ? 0 : (t >= N ? N - 1 : t)) - cb;  // column offset inside this lane's pieces
+        if (tc >= 0 && tc < TNW * 16 && (tc & 15) < 4) {
+          float v = 0.f;
+#pragma unroll
+          for (int ni = 0; ni < TNW; ++ni)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (tc == ni * 16 + e) v = acc[ni][mi][e];
+          ((float*)((float2*)out + (int64_t)M * ldo))[mrow] = v;
+        }
+      }
     } else {
       if (!row_ok) continue;
       float* orow = (float*)out + mrow * ldo;
@@ -397,11 +432,16 @@ static int launch_epi(int dtype, const void* A, const void* W, const float* bias
     // workgroups over the 512 slots; measured +7..9 % on the residual GEMMs, +5 % on gate/up and qkv
     // (tools/gemm_check.py --iters 2000).  Edge tiles clamp their operand rows, so any N works.
     // The fp32-out flavour (LM head, N = 15080) measures 6 % faster on 128-wide tiles.
-    if constexpr (EPI == EPI_F32) return launch_k16<EPI, 128>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
+    if constexpr (EPI == EPI_F32 || EPI == EPI_LSE) return launch_k16<EPI, 128>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
     else return launch_k16<EPI, 192>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
   } else {
-    hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nwg), dim3(256), 0, st, (const float*)A,
-                       (const float*)W, bias, out, M, N, K, ldo, tilesN, nwg);
+    if constexpr (EPI == EPI_LSE) {
+      set_error("gemm: the fused log-sum-exp epilogue exists for bf16 only");
+      return DARK_ERR_UNSUPPORTED;
+    } else {
+      hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nwg), dim3(256), 0, st, (const float*)A,
+                         (const float*)W, bias, out, M, N, K, ldo, tilesN, nwg);
+    }
   }
   DARK_CHECK_LAUNCH();
   return DARK_OK;
@@ -477,6 +517,9 @@ static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, co
       DARK_CHECK_ARG(N % 32 == 0, "gemm: SWIGLU needs N %% 32 == 0 (N=%d)", N);
       return launch_epi<EPI_SWIGLU>(dtype, A, W, bias, out, M, N, K, ldo, st);
     case EPI_F32: return launch_epi<EPI_F32>(dtype, A, W, bias, out, M, N, K, ldo, st);
+    case EPI_LSE:
+      DARK_CHECK_ARG(bias != nullptr && ldo == 2 * cdiv(N, 128), "gemm: EPI_LSE needs targets and ldo = 2*ceil(N/128)");
+      return launch_epi<EPI_LSE>(dtype, A, W, bias, out, M, N, K, ldo, st);
   }
   set_error("gemm: bad epilogue %d", epi);
   return DARK_ERR_ARG;

@@ -176,6 +176,33 @@ int dark_expand_commit_edit(int64_t* x, int B, int N, const int32_t* row_index, 
                             int64_t mask_id, int64_t delete_id, int64_t expand_id, int pad_delete_to_right,
                             int64_t* snaps, int32_t* snap_len, void* stream);
 
+/* ---- forward-only log-probabilities of the diffusion GRPO trainer, as computed under no_grad for
+ * the old / reference policy in akgr/abduction_model/custom_grpo2.py:681-709.
+ *
+ * dark_lm_head_logprob: `F.log_softmax(logits, -1).gather(-1, index)` (:133-134) fused with the final RMSNorm and
+ * the LM head on selected rows: logp[i] = log_softmax(lm_head(norm(hidden[src_rows[i]])))[targets[i]].
+ * bf16 models never materialise the logits (log-sum-exp partials in the GEMM epilogue); fp32 models go through
+ * fp32 logits in chunks of 4096 rows.  src_rows NULL = rows 0..M-1; n_src = rows of `hidden`; targets clamp to [0,V). */
+size_t dark_logprob_workspace_bytes(const dark_model_desc* m, int M);
+int dark_lm_head_logprob(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int n_src,
+                         const int64_t* targets, int M, void* workspace, size_t workspace_bytes, float* logp,
+                         void* stream);
+/* The same second stage on materialised fp32 logits [M, ldl] (selective_log_softmax's inner step, :133-134). */
+int dark_logprob_from_logits(const float* logits, int64_t ldl, const int64_t* targets, int M, int V, float* logp,
+                             void* stream);
+/* forward_process (:373-385): noisy [3,b,l] = {all target tokens masked, masked where rand < t_p, masked where
+ * rand > t_p}; completion_mask [b,l] = (rand < t_p) & target.  mask_target [b,l] uint8, rnd [b,l] fp32 uniforms. */
+int dark_grpo_perturb(const int64_t* batch, const uint8_t* mask_target, const float* rnd, float t_p, int64_t mask_id,
+                      int b, int l, int64_t* noisy, uint8_t* completion_mask, void* stream);
+/* src_rows[s*N+j] = s*N + max(j-1, 0): get_logits' shift `cat([logits[:, :1], logits[:, :-1]])` (:412-414) as a
+ * row gather for dark_lm_head_logprob. */
+int dark_shift_rows(int32_t* src_rows, int S, int N, void* stream);
+/* selective_log_softmax's weighting (:136-152): logp [I*3*B, N] in the order the trainer concatenates the three
+ * versions per iteration; weights [3I] device fp32; mask [I*B, N] uint8 -> out [I*B, N]
+ * = (p0 + (mask ? p1*w1 : p2*w2)) / 2. */
+int dark_grpo_combine(const float* logp, const float* weights, const uint8_t* mask, int I, int B, int N, float* out,
+                      void* stream);
+
 /* ---- measurement hook (no counterpart in the reference): bracket every launch of ONE GEMM flavour
  * (epi as in dark_dbg_gemm; -1 = off) with HIP events on the launch stream.  dark_prof_read waits for
  * the recorded events, returns their summed duration, the algorithmic FLOPs (2*M*N*K) of those launches
@@ -187,7 +214,9 @@ int dark_prof_read(double* total_ms, double* total_flops, int* launches);
 /* ---- unit-test hooks (no counterpart in the reference): launch ONE kernel of the path so that
  * tests/test_hip_kernels.py can pin it against the oracle in isolation.
  *   epi: 0 = +bias (out in model dtype), 1 = residual add into fp32 out, 2 = SwiGLU over interleaved
- *        gate/up rows, groups of 16 (bf16) / 32 (fp32) (out [M, N/2] model dtype), 3 = plain fp32 store.  W has rows padded to 128. */
+ *        gate/up rows, groups of 16 (bf16) / 32 (fp32) (out [M, N/2] model dtype), 3 = plain fp32 store,
+ *        4 = bf16 only, log-sum-exp partials: bias = int64 targets [M], out = float2 [M, ldo = 2*ceil(N/128)] then
+ *        float [M] target logits.  W has rows padded to 128. */
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                   int N, int K, int64_t ldo, void* stream);
 int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
