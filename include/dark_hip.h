@@ -203,6 +203,21 @@ int dark_shift_rows(int32_t* src_rows, int S, int N, void* stream);
 int dark_grpo_combine(const float* logp, const float* weights, const uint8_t* mask, int I, int B, int N, float* out,
                       void* stream);
 
+/* ---- host pre / post steps of the batched evaluation as device kernels.
+ * dark_build_layout: `test_unify_extract_sample_to_device_length` after tokenisation (akgr/tokenizer.py:318-335):
+ * input_ids [B, Q+A+3] = [bos | query | sep | observation | eos] with the query (mode 1, 'sft_abd') or the
+ * observation (mode 2, 'sft_ded') replaced by MASK (mode 0 = 'unify': nothing masked); need_to_mask (nullable)
+ * [B, Q+A+3] fp32 = the reference's `attention_mask` return (1 on the side to generate; both sides for 'unify'). */
+int dark_build_layout(const int64_t* query_ids, const int64_t* observation_ids, int B, int Q, int A, int mode,
+                      int64_t bos_id, int64_t sep_id, int64_t eos_id, int64_t mask_id, int64_t* input_ids,
+                      float* need_to_mask, void* stream);
+/* The SEP split and special-token strip of akgr/abduction_model/main.py:409-421: sep_pos[0] = first SEP of ROW 0
+ * (-1 if none: the reference raises IndexError); left[b] = ids[b, :sep_pos] and right[b] = ids[b, sep_pos+1:] with
+ * the ids `tokenizer.decode(..., skip_special_tokens=True)` drops removed (special_lo: bit i set = id i is
+ * special, ids 0..63), order kept, padded with -1; *_len [B] = kept count. */
+int dark_split_strip(const int64_t* ids, int B, int N, int64_t sep_id, uint64_t special_lo, int64_t* left,
+                     int32_t* left_len, int64_t* right, int32_t* right_len, int32_t* sep_pos, void* stream);
+
 /* ---- measurement hook (no counterpart in the reference): bracket every launch of ONE GEMM flavour
  * (epi as in dark_dbg_gemm; -1 = off) with HIP events on the launch stream.  dark_prof_read waits for
  * the recorded events, returns their summed duration, the algorithmic FLOPs (2*M*N*K) of those launches
