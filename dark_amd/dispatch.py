@@ -115,3 +115,45 @@ def generate_sharded(model, inputs: torch.Tensor, generation_config=None, *, gro
     if not gather:
         return local
     return gather_rows(local, total, group)
+
+
+@torch.no_grad()
+def generate_batch_sharded(model, prompts, generation_config=None, *, group=None, gather: bool = True,
+                           **kwargs) -> torch.Tensor:
+    """Variable-length path: ``model.diffusion_generate_batch`` over this rank's contiguous block of the
+    ragged `prompts` list (same list on every rank), then an all_gather of the `[B_local, max_length]` sequences.
+    Sequences are independent, so nothing is exchanged inside the loop; ranks simply finish at different steps."""
+    world, rank = _world(group)
+    total = len(prompts)
+    lo, hi = shard_bounds(total, world, rank)
+    kwargs = dict(kwargs)
+    kwargs["return_dict_in_generate"] = False
+    n = kwargs.get("max_length") or generation_config.max_length
+    if hi > lo:
+        local = model.diffusion_generate_batch(list(prompts[lo:hi]), generation_config=generation_config, **kwargs)
+    else:
+        local = prompts[0].new_empty((0, n))
+    if not gather:
+        return local
+    return gather_rows(local, total, group)
+
+
+@torch.no_grad()
+def per_token_logps_sharded(model, input_ids: torch.Tensor, mask_attention: torch.Tensor, mask_seeds,
+                            mask_token_id: int, *, group=None, gather: bool = True, **kwargs) -> torch.Tensor:
+    """GRPO scoring with the completions `[I, B, N]` split along B: every rank scores its block with
+    ``grpo_logps.get_per_token_logps`` and the `[B_local, I, N]` results are all-gathered.  The perturbation is
+    drawn per rank (seed + local rows), as the reference's per-process trainers do."""
+    from . import grpo_logps
+    world, rank = _world(group)
+    total = input_ids.shape[1]
+    lo, hi = shard_bounds(total, world, rank)
+    if hi > lo:
+        local = grpo_logps.get_per_token_logps(model, input_ids[:, lo:hi], mask_attention[:, lo:hi], mask_seeds,
+                                               mask_token_id, **kwargs)
+    else:
+        local = torch.empty((0, input_ids.shape[0], input_ids.shape[2]), dtype=torch.float32,
+                            device=input_ids.device)
+    if not gather:
+        return local
+    return gather_rows(local.contiguous(), total, group)

@@ -37,6 +37,14 @@ class _FakeModel:
             x[:, -1] = m * 1000 + b
         return x
 
+    def diffusion_generate_batch(self, prompts, generation_config=None, **kw):
+        assert kw["return_dict_in_generate"] is False
+        n = generation_config.max_length
+        out = torch.full((len(prompts), n), synth.END)
+        for b, p in enumerate(prompts):
+            out[b, :p.shape[1]] = torch.where(p[0] == synth.MASK, 2000 + p.shape[1], p[0])
+        return out
+
 
 def _worker(rank, world, port, total):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -57,6 +65,12 @@ def _worker(rank, world, port, total):
         assert bool((out[:, -1] == m_glob * 1000 + total).all())
         ts = torch.linspace(1, 1e-3, 5)
         assert transfer_count(m_glob, total, ts[0], ts[1], False) == int(torch.tensor(m_glob) / total * (1 - ts[1] / ts[0]))
+        # variable-length path: ragged prompt list, contiguous blocks, gathered [total, max_length]
+        import types
+        prompts = synth.make_var_inputs(total, "abd", 5, seed=9)
+        gc = types.SimpleNamespace(max_length=50)
+        got = dispatch.generate_batch_sharded(model, prompts, gc)
+        assert torch.equal(got, model.diffusion_generate_batch(prompts, gc, return_dict_in_generate=False))
         # metric records
         g = torch.Generator().manual_seed(rank)
         scores = torch.rand(hi - lo, 6, generator=g)
