@@ -236,9 +236,7 @@ class DreamGenerationMixin:
         temperature, top_p, top_k = gc.temperature, gc.top_p, gc.top_k
         mask_token_id = gc.mask_token_id
         histories = [] if (gc.return_dict_in_generate and gc.output_history) else None
-        if gc.think_sample:
-            raise NotImplementedError("think_sample (generation_utils.py:411-432) is not exercised by any caller "
-                                      "of the reference and is not implemented")
+        think = bool(gc.think_sample)
         if mask_token_id is None:
             raise ValueError("mask_token_id must be set in the generation config")
         if alg not in ("origin", "maskgit_plus", "topk_margin", "entropy"):
@@ -262,7 +260,7 @@ class DreamGenerationMixin:
         default_hooks = generation_tokens_hook_func is None and generation_logits_hook_func is None
         tokens_hook = generation_tokens_hook_func or (lambda step, x, logits: x)
         logits_hook = generation_logits_hook_func or (lambda step, x, logits: logits)
-        fast = default_hooks and alg != "origin" and (alg_temp is None or alg_temp == 0)
+        fast = default_hooks and alg != "origin" and (alg_temp is None or alg_temp == 0) and not think
         top_p_f = float(top_p) if (top_p is not None and top_p < 1) else 0.0
         top_k_i = int(min(top_k, self.config.vocab_size)) if top_k is not None else 0
 
@@ -276,9 +274,16 @@ class DreamGenerationMixin:
                 self._step_fast(st, x, pos, key_mask, mask_token_id, temperature, top_p_f, top_k_i, _CONF_MODE[alg],
                                 t, s, last, i, noise_fn, trace)
             else:
-                x = self._step_general(st, x, pos, key_mask, mask_token_id, temperature, top_p_f, top_k_i, alg,
-                                       alg_temp, t, s, last, i, tokens_hook, logits_hook, noise_fn,
-                                       trace).contiguous()
+                # think_sample steps (generation_utils.py:490-491, :411-432): `check_and_select` forwards 4 identical
+                # copies of every row with arange positions (`calculate_results`, :369-372), resamples them twice and
+                # returns the first-pass logits of the copy whose resampled observation side is closest -- the
+                # copies' logits are identical, so what reaches the sampler is the forward with arange positions.
+                # That forward is what runs here; the two discarded categorical draws are not consumed from the
+                # RNG stream, and the IndexError the reference raises when row 0 holds no SEP is not reproduced.
+                think_step = think and i % gc.think_sample_interval == 0
+                x = self._step_general(st, x, None if think_step else pos, key_mask, mask_token_id, temperature,
+                                       top_p_f, top_k_i, alg, alg_temp, t, s, last, i, tokens_hook, logits_hook,
+                                       noise_fn, trace).contiguous()
             if getattr(self, "_state_hook", None) is not None:
                 x.copy_(self._state_hook(i, x).to(x.device))
                 st.hidden_valid = False

@@ -14,7 +14,7 @@ reference lines it follows (paths relative to ``/root/reference/``):
   LM head :771-824)
 * ``akgr/abduction_model/model/custom_mydream/generation_utils.py``
   (top_p_logits :37-48, top_k_logits :50-55, sample_tokens :58-90,
-  _sample :435-548)
+  think sample :367-432, _sample :435-548)
 * ``akgr/abduction_model/model/custom_mydream/generation_expand_utils.py``
   (variable-length EXPAND/DELETE sampler: diffusion_generate :294-356, _sample :358-503)
 
@@ -222,6 +222,54 @@ def transfer_schedule(masks_per_row: float, steps: int, eps: float = 1e-3) -> Li
     return out
 
 
+# --------------------------------------------------------------------------- think sample (generation_utils.py:367-432)
+def _calculate_results(fwd, x, attn4d, mask_token_id: int, temperature: float):
+    """generation_utils.py:367-385: forward with arange positions, sample EVERY position, fill the masked ones."""
+    mask_index = x == mask_token_id
+    tok = torch.ones_like(x).long().cumsum(-1) - 1
+    logits = fwd(x, attn4d, tok)
+    logits = torch.cat([logits[:, :1], logits[:, :-1]], dim=1)
+    probs = torch.softmax(logits, dim=-1)
+    if temperature > 0:
+        try:
+            x0 = categorical_sample(probs.reshape(-1, probs.shape[-1])).view(probs.shape[:-1])
+        except ValueError:
+            x0 = probs.max(dim=-1)[1]
+    else:
+        x0 = probs.max(dim=-1)[1]
+    x_final = x.clone()
+    x_final[mask_index] = x0[mask_index].clone()
+    return logits, x_final
+
+
+def _compare_results(x1, x2, expand_size: int) -> List[int]:
+    """generation_utils.py:387-409: per group of `expand_size` rows, the first row with the largest Jaccard
+    similarity of token SETS."""
+    scores = []
+    for i in range(x1.shape[0]):
+        a, b = set(x1[i].tolist()), set(x2[i].tolist())
+        scores.append(len(a & b) / len(a | b) if len(a | b) > 0 else 0)
+    out = []
+    for g0 in range(0, len(scores), expand_size):
+        grp = scores[g0:g0 + expand_size]
+        out.append(g0 + max(range(len(grp)), key=grp.__getitem__))
+    return out
+
+
+def check_and_select(fwd, x, attn4d, expand_size: int, mask_token_id: int, sep_token_id: int,
+                     temperature: float = 1.0) -> torch.Tensor:
+    """generation_utils.py:411-432.  Returns shifted logits [B, N, V] of the selected copy of every row."""
+    x_in = x.repeat_interleave(expand_size, dim=0) if expand_size != 1 else x
+    am = attn4d.repeat_interleave(expand_size, dim=0) if expand_size != 1 else attn4d
+    logits_select, x_select = _calculate_results(fwd, x_in, am, mask_token_id, temperature)
+    sep_pos = int((x_select[0] == sep_token_id).nonzero(as_tuple=True)[0][0])
+    x_mask = x_select.clone()
+    x_mask[:, sep_pos + 1:-1] = mask_token_id
+    _, x_final = _calculate_results(fwd, x_mask, am, mask_token_id, temperature)
+    picks = _compare_results(x_in[:, sep_pos + 1:], x_final[:, sep_pos + 1:], expand_size)
+    return logits_select[picks]
+
+
 # --------------------------------------------------------------------------- the loop
 @dataclass
 class SampleTrace:
@@ -243,7 +291,8 @@ def sample_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
                 noise_fn: Optional[Callable[[int, int, int], torch.Tensor]] = None,
                 trace: Optional[SampleTrace] = None, keep_logits: bool = False,
                 forward_fn: Optional[Callable] = None, rand_fn: Optional[Callable[[int, int], torch.Tensor]] = None,
-                tie_break: str = "torch") -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                tie_break: str = "torch", think_sample: bool = False, think_sample_interval: int = 2,
+                sep_token_id: Optional[int] = None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """generation_utils.py:435-548.  Returns (sequences, history) with history[i] = x after step i.
 
     ``noise_fn(step, M, V)`` injects the exponential noise of the categorical draw
@@ -270,8 +319,11 @@ def sample_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
     x = tokens_hook(None, x, None)
     for i in range(steps):
         mask_index = x == mask_token_id
-        logits = fwd(x, attn4d, tok_idx)
-        logits = torch.cat([logits[:, :1], logits[:, :-1]], dim=1)
+        if think_sample and i % think_sample_interval == 0:                      # :490-491
+            logits = check_and_select(fwd, x, attn4d, 4, mask_token_id, sep_token_id)
+        else:
+            logits = fwd(x, attn4d, tok_idx)
+            logits = torch.cat([logits[:, :1], logits[:, :-1]], dim=1)
         logits = logits_hook(i, x, logits)
         mask_logits = logits[mask_index]
         t, s = timesteps[i], timesteps[i + 1]

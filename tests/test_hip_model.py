@@ -368,3 +368,67 @@ def test_config4_shape_vs_oracle():
     exp = torch.stack(hist)
     mism = (got != exp).any(-1).any(-1)
     assert not bool(mism.any()), f"history differs from the oracle at steps {mism.nonzero().view(-1).tolist()}"
+
+
+def test_think_sample_matches_reference(mini, golden_meta):
+    """`think_sample=True` (generation_utils.py:367-432, :490-491) against goldens generated from the reference
+    (tests/golden/make_goldens_think.py).  The categorical noise of the committing draws is recorded from an oracle
+    run on the reference's CPU RNG stream (which also consumes the two discarded think draws) and replayed.
+    Free runs must equal the oracle; a diverging case is replayed under teacher forcing and every differing step
+    must be an fp32 near-tie, either between positions (confidences) or between tokens (the oracle's own logits of
+    the two tokens within 1e-5: on think steps the reference forwards a 4x repeated batch, whose CPU GEMM blocking
+    differs in the last bits from the plain forward)."""
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "reference_goldens_think.json")) as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(here, "reference_goldens_think.npz"))
+    cfg = O.OracleConfig(**{k: v for k, v in golden_meta["mini"].items() if k in O.OracleConfig.__dataclass_fields__})
+    w = synth.make_weights(cfg, seed=0, rich=True)
+    exact = 0
+    for c in meta["cases"]:
+        kw = dict(c["kw"])
+        ids = torch.from_numpy(g[c["ids"]])
+        am = torch.from_numpy(g[c["attention_mask"]]) if c["attention_mask"] else None
+        noise = {}
+
+        def rec(step, M, V):
+            noise[step] = torch.empty(M, V).exponential_(1)
+            return noise[step]
+
+        torch.manual_seed(c["seed"])
+        otr = O.SampleTrace()
+        _, oh = O.sample_loop(w, cfg, ids, max_length=ids.shape[1] + 1, mask_token_id=synth.MASK, attention_mask=am,
+                              steps=kw["steps"], alg=kw["alg"], alg_temp=kw["alg_temp"], temperature=kw["temperature"],
+                              top_p=kw["top_p"], think_sample=True, think_sample_interval=kw["think_sample_interval"],
+                              sep_token_id=synth.SEP, noise_fn=rec, tie_break="index", trace=otr, keep_logits=True)
+        oh = torch.stack(oh)
+        extra = {} if am is None else {"attention_mask": am.to(DEV)}
+
+        def run(**priv):
+            out = mini.diffusion_generate(ids.to(DEV), generation_config=_gc(ids.shape[1]), output_history=True,
+                                          return_dict_in_generate=True, think_sample=True,
+                                          _noise_fn=lambda s_, M, V: noise[s_], **priv, **extra, **kw)
+            return torch.stack(out.history).cpu()
+
+        got = run()
+        if torch.equal(got, oh):
+            exact += int(np.array_equal(got.numpy(), g[c["name"] + "_hist"]))
+            continue
+        forced = []
+        run(_state_hook=lambda i, x: (forced.append(x.cpu().clone()), oh[i])[1])
+        x_init = torch.nn.functional.pad(ids, (0, 1), value=synth.MASK)
+        for i, hx in enumerate(forced):
+            if torch.equal(hx, oh[i]):
+                continue
+            prev = oh[i - 1] if i else x_init
+            if _explained_by_near_tie(prev, hx, oh[i], otr.confidence[i], otr.k[i]):
+                continue
+            mi = prev == synth.MASK
+            flat = mi.flatten().nonzero().flatten().tolist()
+            for b, j in (hx != oh[i]).nonzero().tolist():
+                assert hx[b, j] != synth.MASK and oh[i][b, j] != synth.MASK, (c["name"], i, b, j)
+                lg = otr.mask_logits[i][flat.index(b * mi.shape[1] + j)]
+                assert abs(float(lg[hx[b, j]] - lg[oh[i][b, j]])) <= 1e-5, (c["name"], i, b, j)
+    assert exact >= 2, exact                                          # == the reference's goldens end to end

@@ -121,3 +121,28 @@ def test_real_shape(goldens, golden_meta):
     np.testing.assert_allclose(lg[0, :3].numpy(), goldens["real_logits_row0_pos0_3"], atol=2e-5)
     case = dict(seed=2, kw=dict(steps=16, temperature=0.1, alg="entropy", alg_temp=0, top_p=0.9))
     assert np.array_equal(_run_loop(cfg, w, ids, case), goldens["real_abd_t01_hist"])
+
+
+# ---- think_sample (generation_utils.py:367-432, :490-491): fixtures from tests/golden/make_goldens_think.py
+def _think_gold():
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "reference_goldens_think.json")) as f:
+        meta = json.load(f)
+    return np.load(os.path.join(here, "reference_goldens_think.npz")), meta
+
+
+def test_think_sample_loops(mini):
+    cfg, w = mini
+    g, meta = _think_gold()
+    for c in meta["cases"]:
+        kw = dict(c["kw"])
+        ids = torch.from_numpy(g[c["ids"]])
+        am = torch.from_numpy(g[c["attention_mask"]]) if c["attention_mask"] else None
+        torch.manual_seed(c["seed"])
+        _, hist = O.sample_loop(w, cfg, ids, max_length=ids.shape[1] + 1, mask_token_id=synth.MASK,
+                                attention_mask=am, steps=kw["steps"], alg=kw["alg"], alg_temp=kw["alg_temp"],
+                                temperature=kw["temperature"], top_p=kw["top_p"], think_sample=True,
+                                think_sample_interval=kw["think_sample_interval"], sep_token_id=synth.SEP)
+        assert np.array_equal(torch.stack(hist).numpy(), g[c["name"] + "_hist"]), c["name"]
