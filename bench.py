@@ -160,8 +160,8 @@ def main():
                    "top_p": 0.9, "alg": "entropy", "parallelism": f"dp{world}", "weights": "random-init"},
         "value_skip_noop_steps": round(args.batch * world * args.steps / dt_skip, 2),
         "forward_mfma_frac": round(alg_flops * args.steps * world / dt / 1e12 / (peak * world), 4),
-        "roofline": {"bound": "mfma", "kernel": f"gemm_{args.dtype}_kernel16<EPI_SWIGLU> (gate/up projection + SiLU*up, "
-                                                "M=B*N/2 rows per call, N=6144, K=768)",
+        "roofline": {"bound": "mfma", "kernel": (("gemm_bf16_kernel16<2, 192>" if args.dtype == "bf16" else "gemm_f32_kernel<2>")
+                                + " = EPI_SWIGLU (gate/up projection + SiLU*up, M=B*N/2 rows per call, N=6144, K=768)"),
                      "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4),
                      # HBM-side bytes per launch from rocprofv3 PMC (FETCH_SIZE doubled per the gfx950 note, +
