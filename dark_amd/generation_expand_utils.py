@@ -152,7 +152,7 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
         trace = kwargs.pop("_trace", None)         # parity tests: dict receiving per-step M / conf / x0 / rows
         compact = kwargs.pop("compact_finished", True)
         # parity tests, teacher forcing: step -> (x [B, max_length], win [B], budget [B]) or None to stop
-        self._expand_state_hook = kwargs.pop("_state_hook", None)
+        state_hook = kwargs.pop("_state_hook", None)
         gc = self._prepare_generation_config(generation_config, **kwargs)
         attention_mask = kwargs.pop("attention_mask", None)
         assert attention_mask is None, ("We currently do not support attention_mask for DreamOn since we recompute "
@@ -192,11 +192,12 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
                 f" is on {self.device.type}. You may experience unexpected behaviors or slower generation.",
                 UserWarning)
         return self._sample(packed, prefixes, n_masks, gc, _single=single, _noise_fn=noise_fn, _trace=trace,
-                            _compact=compact)
+                            _compact=compact, _state_hook=state_hook)
 
     # ------------------------------------------------------------------ the loop
     def _sample(self, input_ids, prefix_len, start_gen_len, generation_config, _single: Optional[bool] = None,
-                _noise_fn: Optional[Callable] = None, _trace: Optional[dict] = None, _compact: bool = True):
+                _noise_fn: Optional[Callable] = None, _trace: Optional[dict] = None, _compact: bool = True,
+                _state_hook: Optional[Callable] = None):
         """generation_expand_utils.py:358-503 for every row at once.  `input_ids`: a `[1, L]` tensor with scalar
         `prefix_len` / `start_gen_len` (the reference signature) or lists of them."""
         gc = generation_config
@@ -254,8 +255,7 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
         st = self._hip_state(B, N)
         buf = _ExpandBuffers(B, N, device, want_history)
         lib, s = st.lib, st._s()
-        state_hook = getattr(self, "_expand_state_hook", None)
-        self._expand_state_hook = None
+        state_hook = _state_hook
         if state_hook is not None:
             _compact = False
         for i in range(max(limit0)):
