@@ -129,11 +129,52 @@ __global__ __launch_bounds__(1024) void mask_rows_kernel(const int64_t* __restri
   if (tid == 0) *count = all;
 }
 
+// Multi-workgroup variant for the usual sizes: workgroup w owns elements [1024w, 1024w + 1024).  Its output offset is
+// the number of masks before it, which it counts itself from the (L2-resident, <= 2 MB) id array: no scratch buffer
+// and no second launch; 38 -> 7 us at B*N = 23552.
+__global__ __launch_bounds__(1024) void mask_rows_tiled_kernel(const int64_t* __restrict__ x, int total, int N,
+                                                               int64_t mask_id, int32_t* __restrict__ row_index,
+                                                               int32_t* __restrict__ src_rows,
+                                                               int32_t* __restrict__ count) {
+  __shared__ int wave_tot[16];
+  __shared__ int before_sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int first = blockIdx.x * 1024;
+  int before = 0;
+  for (int f = tid; f < first; f += 1024) before += (x[f] == mask_id);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  if (tid == 0) before_sh = 0;
+  __syncthreads();
+  if (lane == 0 && before) atomicAdd(&before_sh, before);
+  const int f = first + tid;
+  const bool flag = f < total && x[f] == mask_id;
+  const unsigned long long bal = __ballot(flag);
+  if (lane == 0) wave_tot[wave] = __popcll(bal);
+  __syncthreads();
+  int off = before_sh, all = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) off += wave_tot[w];
+    all += wave_tot[w];
+  }
+  if (flag) {
+    off += __popcll(bal & ((1ull << lane) - 1ull));
+    row_index[off] = f;
+    src_rows[off] = (f % N == 0) ? f : f - 1;
+  }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) *count = before_sh + all;
+}
+
 int launch_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* row_index, int32_t* src_rows,
                      int32_t* count, hipStream_t st) {
   DARK_CHECK_ARG(B > 0 && N > 0 && (int64_t)B * N < (1ll << 30), "mask_rows: bad B=%d N=%d", B, N);
-  hipLaunchKernelGGL(mask_rows_kernel, dim3(1), dim3(1024), 0, st, x, B * N, N, mask_id, row_index, src_rows,
-                     count);
+  const int total = B * N, nb = cdiv(total, 1024);
+  if (nb <= 256)
+    hipLaunchKernelGGL(mask_rows_tiled_kernel, dim3(nb), dim3(1024), 0, st, x, total, N, mask_id, row_index, src_rows,
+                       count);
+  else
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(1), dim3(1024), 0, st, x, total, N, mask_id, row_index, src_rows,
+                       count);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }

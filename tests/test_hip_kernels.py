@@ -258,7 +258,8 @@ def _commit_ref(x, mask_id, conf, x0, k):
     return x
 
 
-@pytest.mark.parametrize("B,N,k", [(8, 46, 1), (8, 46, 3), (64, 46, 11), (5, 128, 7), (3, 200, 4)])
+@pytest.mark.parametrize("B,N,k", [(8, 46, 1), (8, 46, 3), (64, 46, 11), (5, 128, 7), (3, 200, 4), (1024, 46, 2),
+                                   (2100, 128, 3)])  # the last one exceeds 256 tiles: single-workgroup kernel
 def test_mask_rows_and_commit(lib, B, N, k):
     H = _hip()
     g = torch.Generator().manual_seed(B * N + k)
