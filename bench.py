@@ -10,7 +10,9 @@ deductive+abductive evaluation batch of 1024 sequences per GPU (512 abduction ro
 rows with 33 masks, as two `diffusion_generate` calls -- the reference never mixes layouts in one call,
 custom_grpo2.py:593-599), 32 denoise steps each, temperature 0.1, top_p 0.9, alg 'entropy' (main.py:393-404),
 bf16 weights/activations with fp32 accumulation, default model shape (10 x d768 x ff3072, V = 15080).
-Every denoise step runs its full forward + head + sampling; nothing is cached or skipped.
+Every denoise step runs its full forward + head + sampling; nothing is cached or skipped (the categorical noise is
+the same torch Philox stream the reference consumes, evaluated inside the sampler: --materialise-noise fills it with
+torch instead, same results).
 Inputs are synthetic (dark_amd.synth), resident in HBM before the timed region; weights are random-init.
 Multi-GPU: rows are sharded data-parallel (weak scaling: 1024 sequences per GPU), no collective inside the loop;
 the per-batch result gather (sequences, fixed-width records) over RCCL is inside the timed region.
@@ -61,6 +63,8 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--materialise-noise", action="store_true",
+                    help="fill the [M,V] categorical noise with torch instead of computing it in the sampler")
     ap.add_argument("--cpu-sample", type=int, default=48, help="sequences in the CPU-oracle sample")
     args = ap.parse_args()
 
@@ -91,7 +95,8 @@ def main():
     gc = DreamGenerationConfig(mask_token_id=synth.MASK, pad_token_id=synth.END, bos_token_id=synth.BOS,
                                eos_token_id=synth.END, sep_token_id=synth.SEP, max_length=46)
     gen_kw = dict(steps=args.denoise_steps, temperature=0.1, alg="entropy", alg_temp=0, top_p=0.9,
-                  number_transfer_tokens=1, skip_noop_steps=False)  # headline: every step runs its forward
+                  number_transfer_tokens=1, skip_noop_steps=False,  # headline: every step runs its forward
+                  lazy_noise=not args.materialise_noise)
     torch.manual_seed(2 + rank)
 
     import warnings

@@ -51,6 +51,10 @@ SIGNATURES = {
                                  C.c_void_p]),
     "dark_sample_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dark_sample_rows_philox": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                          C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    "dark_philox_exponential": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "dark_commit_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_void_p]),
     "dark_denoise_step": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -179,6 +179,20 @@ int dark_sample_rows(const float* logits, int64_t ldl, int M, int V, float tempe
                        (hipStream_t)stream);
 }
 
+int dark_sample_rows_philox(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
+                            int conf_mode, uint64_t seed, uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0,
+                            void* stream) {
+  DARK_CHECK_ARG(nthreads > 0 && nthreads % 256 == 0, "sample_rows_philox: nthreads=%u must be a positive multiple of 256",
+                 nthreads);
+  return launch_sample_philox(logits, ldl, M, V, temperature, top_p, top_k, conf_mode, nullptr, 0, seed, offset,
+                              nthreads, conf, x0, (hipStream_t)stream);
+}
+
+int dark_philox_exponential(uint64_t seed, uint64_t offset, uint32_t nthreads, uint64_t numel, float* out,
+                            void* stream) {
+  return launch_philox_exponential(seed, offset, nthreads, numel, out, (hipStream_t)stream);
+}
+
 int dark_commit_topk(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M, const float* conf,
                      const int64_t* x0, int k, void* stream) {
   DARK_CHECK_ARG(x && (M == 0 || (row_index && conf && x0)), "commit_topk: null pointer");

@@ -125,6 +125,12 @@ int launch_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* r
 int launch_sample(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p,
                   int top_k, int conf_mode, const float* noise, int64_t ldn, float* conf, int64_t* x0,
                   hipStream_t st);
+// noise == NULL and nthreads > 0: the Exp(1) draws are computed in place from torch's Philox stream (sample.hip)
+int launch_sample_philox(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
+                         int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
+                         uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st);
+int launch_philox_exponential(uint64_t seed, uint64_t offset, uint32_t nthreads, uint64_t numel, float* out,
+                              hipStream_t st);
 int launch_commit(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M,
                   const float* conf, const int64_t* x0, int k, hipStream_t st);
 

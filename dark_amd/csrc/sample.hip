@@ -22,6 +22,7 @@
 // Draw: x0 = argmax_i (p_i / psum) / q_i with q ~ Exp(1) supplied by the caller, which is the ATen
 // multinomial(1) that Categorical(probs).sample() runs; ties -> lowest index (torch argmax).
 #include "common.h"
+#include <rocrand/rocrand_kernel.h>
 
 namespace dark {
 
@@ -304,9 +305,43 @@ __device__ int nucleus_crossing(const float* row, int V, float mx, float top_p, 
   return resolve_candidates(cand, cfx, c, A, T, s, tid, tau, above, n_tau);
 }
 
+// ------------------------------------------------------------------ lazy categorical noise
+// Element `li` of what `torch.empty(numel).exponential_()` writes on this device for a generator at (seed, offset):
+// ATen's distribution_elementwise_grid_stride_kernel runs `nthreads` threads, thread t = li % nthreads draws its
+// n-th rocrand_uniform4 (Philox4x32-10, subsequence t, offset + 4n) for the elements li = t + nthreads*(4n + ii) and
+// applies transformation::exponential (ATen/core/TransformationHelper.h).  Computing it where it is consumed
+// replaces an [M, V] fp32 fill (up to 1 GB per step) by a few Philox calls per row; the values are identical.
+struct PhiloxNoise {
+  unsigned long long seed, offset;
+  unsigned int nthreads;  // 0: noise comes from memory
+};
+__device__ __forceinline__ float philox_exponential(const PhiloxNoise& pn, unsigned long long li) {
+  const unsigned long long q = li / pn.nthreads;
+  const unsigned int t = (unsigned int)(li - q * pn.nthreads);
+  rocrand_state_philox4x32_10 st;
+  rocrand_init(pn.seed, t, pn.offset + 4ull * (q >> 2), &st);
+  const uint4 raw = rocrand4(&st);
+  const unsigned int ii = (unsigned int)(q & 3);
+  const unsigned int rv = ii == 0 ? raw.x : (ii == 1 ? raw.y : (ii == 2 ? raw.z : raw.w));
+  const float v = fmaf((float)rv, ROCRAND_2POW32_INV, ROCRAND_2POW32_INV);  // rocrand uniform_distribution: (0, 1]
+  // transformation::exponential with lambda = 1.  The log torch's wheel was built with is the hardware log2 times
+  // ln 2 with a single rounding (found by bit-comparison on 85 M values, tools/philox_check.py; the library logf of
+  // this ROCm release differs from it in the last bit for a third of the arguments).
+  const float eps_half = 1.1920928955078125e-07f / 2;
+  const float lgv = (float)((double)__builtin_amdgcn_logf(v) * 0.6931471805599453);
+  const float lg = v >= 1.0f - eps_half ? -eps_half : lgv;
+  return -1.0f / 1.0f * lg;
+}
+
+__global__ __launch_bounds__(256) void philox_exponential_kernel(PhiloxNoise pn, unsigned long long numel,
+                                                                 float* __restrict__ out) {
+  const unsigned long long li = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  if (li < numel) out[li] = philox_exponential(pn, li);
+}
+
 __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ logits, int64_t ldl, int V,
                                                     float temperature, float top_p, int top_k, int conf_mode,
-                                                    const float* __restrict__ noise, int64_t ldn,
+                                                    const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
                                                     float* __restrict__ conf, int64_t* __restrict__ x0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int vp = (V + 3) & ~3;
@@ -480,15 +515,19 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   // 5. draw (generation_utils.py:68-75): argmax of (p / psum) / q; entries with p == 0 give 0 and never win
   if (temperature > 0.f) {
     const float* qr = noise + (int64_t)m * ldn;
+    const unsigned long long q0 = (unsigned long long)m * V;  // the lazy noise is an [M, V] fill
     bestp = -INFINITY;
     besti = 0x7fffffff;
     if (list) {
-      if (my_p > 0.f) { bestp = (my_p / psum) / qr[my_idx]; besti = my_idx; }
+      if (my_p > 0.f) {
+        bestp = (my_p / psum) / (pn.nthreads ? philox_exponential(pn, q0 + my_idx) : qr[my_idx]);
+        besti = my_idx;
+      }
     } else {
       for (int i = tid; i < V; i += ST) {
         const float p = row[i];
         if (p > 0.f) {
-          const float r = (p / psum) / qr[i];
+          const float r = (p / psum) / (pn.nthreads ? philox_exponential(pn, q0 + i) : qr[i]);
           if (r > bestp) { bestp = r; besti = i; }
         }
       }
@@ -536,14 +575,33 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   }
 }
 
+int launch_philox_exponential(uint64_t seed, uint64_t offset, uint32_t nthreads, uint64_t numel, float* out,
+                              hipStream_t st) {
+  DARK_CHECK_ARG(out && nthreads > 0 && numel > 0 && numel < (1ull << 40), "philox_exponential: bad argument");
+  const PhiloxNoise pn{seed, offset, nthreads};
+  hipLaunchKernelGGL(philox_exponential_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, st, pn,
+                     (unsigned long long)numel, out);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
 int launch_sample(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
                   int conf_mode, const float* noise, int64_t ldn, float* conf, int64_t* x0, hipStream_t st) {
+  return launch_sample_philox(logits, ldl, M, V, temperature, top_p, top_k, conf_mode, noise, ldn, 0, 0, 0, conf, x0,
+                              st);
+}
+
+int launch_sample_philox(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
+                         int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
+                         uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st) {
   if (M <= 0) return DARK_OK;
   DARK_CHECK_ARG(V >= 2 && V <= 32768, "sample_rows: V=%d must be in [2, 32768]", V);
   DARK_CHECK_ARG(ldl >= V, "sample_rows: ldl < V");
   DARK_CHECK_ARG(logits && conf && x0, "sample_rows: null pointer");
   DARK_CHECK_ARG(conf_mode >= 0 && conf_mode <= 2, "sample_rows: bad conf_mode %d", conf_mode);
-  DARK_CHECK_ARG(!(temperature > 0.f) || (noise && ldn >= V), "sample_rows: temperature > 0 needs noise [M,V]");
+  DARK_CHECK_ARG(!(temperature > 0.f) || nthreads > 0 || (noise && ldn >= V),
+                 "sample_rows: temperature > 0 needs noise [M,V] or a Philox state");
+  const PhiloxNoise pn{seed, offset, nthreads};
   DARK_CHECK_ARG(temperature >= 0.f, "sample_rows: negative temperature");
   static_assert(NRAD * 12 <= NLIN * 8, "the radix histograms alias the linear histogram");
   const int smem = ((V + 3) & ~3) * 4 + NLIN * 8 + CAND_CAP * 16 + (int)sizeof(Scratch);
@@ -553,7 +611,7 @@ int launch_sample(const float* logits, int64_t ldl, int M, int V, float temperat
     attr_smem = smem;
   }
   hipLaunchKernelGGL(sample_kernel, dim3(M), dim3(ST), smem, st, logits, ldl, V, temperature, top_p, top_k,
-                     conf_mode, noise, ldn, conf, x0);
+                     conf_mode, noise, ldn, pn, conf, x0);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }

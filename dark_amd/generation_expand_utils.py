@@ -151,6 +151,7 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
         noise_fn = kwargs.pop("_noise_fn", None)   # parity tests: (row, step, M_row, V) -> Exp(1) draws
         trace = kwargs.pop("_trace", None)         # parity tests: dict receiving per-step M / conf / x0 / rows
         compact = kwargs.pop("compact_finished", True)
+        self._lazy_noise = bool(kwargs.pop("lazy_noise", True))   # see generation_utils.diffusion_generate
         # parity tests, teacher forcing: step -> (x [B, max_length], win [B], budget [B]) or None to stop
         state_hook = kwargs.pop("_state_hook", None)
         gc = self._prepare_generation_config(generation_config, **kwargs)
@@ -294,7 +295,7 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
             logits = st.head_rows(st.src_rows, M)
             _hip.check(lib.dark_expand_block_logit(_hip.ptr(logits), V, V, _hip.ptr(st.row_index), M, B, N,
                                                    _hip.ptr(win), _hip.ptr(budget), int(expand_id), s))
-            noise = None
+            noise = philox = None
             if temperature > 0:
                 if _noise_fn is not None:
                     seq_of = (st.row_index[:M] // N).tolist()
@@ -304,12 +305,19 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
                     noise = torch.cat([_noise_fn(origin_host[b_live], i, m_b, V).to(torch.float32)
                                        for b_live, m_b in per.items()]).to(device).contiguous()
                     assert noise.shape == (M, V)
+                elif getattr(self, "_lazy_noise", False):
+                    philox = _fixed.philox_fill_plan(device, M * V)
                 else:
                     noise = torch.empty((M, V), device=device, dtype=torch.float32).exponential_()
             conf, x0 = st.conf[:M], st.x0[:M]
-            _hip.check(lib.dark_sample_rows(_hip.ptr(logits), V, M, V, temperature, top_p_f, top_k_i,
-                                            _CONF_MODE[alg], _hip.ptr(noise), V if noise is not None else 0,
-                                            _hip.ptr(conf), _hip.ptr(x0), s))
+            if philox is not None:
+                _hip.check(lib.dark_sample_rows_philox(_hip.ptr(logits), V, M, V, temperature, top_p_f, top_k_i,
+                                                       _CONF_MODE[alg], philox[0], philox[1], philox[2],
+                                                       _hip.ptr(conf), _hip.ptr(x0), s))
+            else:
+                _hip.check(lib.dark_sample_rows(_hip.ptr(logits), V, M, V, temperature, top_p_f, top_k_i,
+                                                _CONF_MODE[alg], _hip.ptr(noise), V if noise is not None else 0,
+                                                _hip.ptr(conf), _hip.ptr(x0), s))
             if _trace is not None:
                 _trace.setdefault("M", []).append(M)
                 _trace.setdefault("rows", []).append([origin_host[b] for b in (st.row_index[:M] // N).tolist()])

@@ -111,6 +111,22 @@ def transfer_count(num_masked: int, batch: int, t: torch.Tensor, s: torch.Tensor
     return int(num_mask_token) if last else int(num_mask_token * (1 - s / t))
 
 
+def philox_fill_plan(device: torch.device, numel: int) -> Tuple[int, int, int]:
+    """Reserve, on torch's device generator, exactly what ``torch.empty(numel, device=device).exponential_()`` would
+    consume, and return (seed, offset, nthreads) for ``dark_sample_rows_philox`` to reproduce that fill lazily.
+    ATen's launch plan (ATen/native/cuda/DistributionTemplates.h, calc_execution_policy): 256-thread blocks,
+    grid = min(CUs * (max threads per CU / 256), ceil(numel / 256)), 4 values per Philox call."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    props = torch.cuda.get_device_properties(idx)
+    grid = min(props.multi_processor_count * (props.max_threads_per_multi_processor // 256), (numel + 255) // 256)
+    nthreads = grid * 256
+    gen = torch.cuda.default_generators[idx]
+    seed, offset = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(offset + ((numel - 1) // (nthreads * 4) + 1) * 4)
+    return seed, offset, nthreads
+
+
 class DreamGenerationMixin:
     """Drop-in for the reference mixin; the model class supplies the ``_hip_*`` launch helpers."""
 
@@ -193,6 +209,10 @@ class DreamGenerationMixin:
         # schedule makes 22/54 of them): their only observable effect is the RNG draw.  With skip_noop_steps the
         # loop keeps that draw and reuses the hidden states of the unchanged x instead of recomputing them.
         self._skip_noop = bool(kwargs.pop("skip_noop_steps", True))
+        # The Exp(1) draws of Categorical.sample() are computed inside the sampler from torch's Philox stream (same
+        # generator state, same values as the [M, V] `exponential_` fill the reference makes) instead of being
+        # written to and read back from HBM; False materialises them with torch.
+        self._lazy_noise = bool(kwargs.pop("lazy_noise", True))
 
         assert inputs is not None
         input_ids = inputs
@@ -321,10 +341,15 @@ class DreamGenerationMixin:
             trace.setdefault("M", []).append(M)
         if M == 0:
             return
-        noise = self._draw_noise(step, M, V, x.device, noise_fn) if temperature > 0 else None
+        noise = philox = None
+        if temperature > 0:
+            if noise_fn is None and getattr(self, "_lazy_noise", False):
+                philox = philox_fill_plan(x.device, M * V)
+            else:
+                noise = self._draw_noise(step, M, V, x.device, noise_fn)
         if skip and k == 0:
             return  # nothing is committed: the draw above was this step's only effect
-        conf, x0 = st.head_and_sample(M, temperature, top_p, top_k, conf_mode, noise)
+        conf, x0 = st.head_and_sample(M, temperature, top_p, top_k, conf_mode, noise, philox)
         if trace is not None:
             trace.setdefault("confidence", []).append(conf.clone())
             trace.setdefault("x0", []).append(x0.clone())

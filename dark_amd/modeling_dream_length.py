@@ -192,10 +192,16 @@ class HipState:
                                              _hip.ptr(x0), self._s()))
         return conf, x0
 
-    def head_and_sample(self, M, temperature, top_p, top_k, conf_mode, noise):
+    def head_and_sample(self, M, temperature, top_p, top_k, conf_mode, noise, philox=None):
+        """`philox` = (seed, offset, nthreads) from generation_utils.philox_fill_plan: draws computed in the kernel."""
         V = self.cfg.vocab_size
         logits = self.head_rows(self.src_rows, M)
         conf, x0 = self.conf[:M], self.x0[:M]
+        if philox is not None:
+            _hip.check(self.lib.dark_sample_rows_philox(_hip.ptr(logits), V, M, V, float(temperature), float(top_p),
+                                                        int(top_k), int(conf_mode), philox[0], philox[1], philox[2],
+                                                        _hip.ptr(conf), _hip.ptr(x0), self._s()))
+            return conf, x0
         _hip.check(self.lib.dark_sample_rows(_hip.ptr(logits), V, M, V, float(temperature), float(top_p),
                                              int(top_k), int(conf_mode), _hip.ptr(noise),
                                              noise.stride(0) if noise is not None else 0, _hip.ptr(conf),

@@ -119,6 +119,19 @@ int dark_sample_rows(const float* logits, int64_t ldl, int M, int V, float tempe
                      int top_k, int conf_mode, const float* noise, int64_t ldn, float* conf,
                      int64_t* x0, void* stream);
 
+/* dark_sample_rows with the Exp(1) draws computed where they are consumed instead of read from a [M, V] buffer:
+ * element (m, v) is element m*V + v of what `torch.empty(M, V).exponential_()` writes on this device for a generator
+ * at (seed, offset) -- ATen's grid-stride kernel over `nthreads` threads, Philox4x32-10 through rocRAND's
+ * rocrand_uniform4, transformation::exponential -- so `Categorical.sample()` (generation_utils.py:70) sees the same
+ * numbers while the 4*M*V-byte fill and its read disappear.  The caller advances the generator by
+ * ((M*V - 1) / (4*nthreads) + 1) * 4, as ATen does (dark_amd/generation_utils.py:philox_fill_plan).
+ * dark_philox_exponential materialises the same stream (tests: bit-equality with torch). */
+int dark_sample_rows_philox(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
+                            int conf_mode, uint64_t seed, uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0,
+                            void* stream);
+int dark_philox_exponential(uint64_t seed, uint64_t offset, uint32_t nthreads, uint64_t numel, float* out,
+                            void* stream);
+
 /* Confidence-ranked commit (generation_utils.py:522-534 with alg_temp in {None, 0}):
  * per row, the k positions with the largest confidence (non-masked positions count as -inf, ties
  * go to the lower index) receive x0 if masked, mask_id otherwise (the re-mask quirk).

@@ -299,3 +299,51 @@ def test_error_paths(lib):
         H.check(lib.dark_sample_rows(H.ptr(a), 100, 4, 100, 0.5, 0.9, 0, 2, None, 0, H.ptr(c), H.ptr(i), _s()))
     with pytest.raises(H.DarkHipError):  # K not a multiple of 64
         H.check(lib.dark_dbg_gemm(0, 3, H.ptr(a), H.ptr(a), None, H.ptr(a), 4, 4, 100, 4, _s()))
+
+
+def _fill_plan(numel):
+    props = torch.cuda.get_device_properties(0)
+    grid = min(props.multi_processor_count * (props.max_threads_per_multi_processor // 256), (numel + 255) // 256)
+    return grid * 256, ((numel - 1) // (grid * 256 * 4) + 1) * 4
+
+
+@pytest.mark.parametrize("numel", [1, 7, 256, 1000, 15080 * 11, 2048 * 256 * 4 + 5, 15080 * 2000])
+def test_philox_exponential_is_torchs_stream(lib, numel):
+    """dark_philox_exponential == torch.empty(numel).exponential_() bit for bit, and the generator offset ATen
+    reserves for that fill is the one dark_amd.generation_utils.philox_fill_plan reserves."""
+    H = _hip()
+    gen = torch.cuda.default_generators[0]
+    torch.manual_seed(4321 + numel)
+    torch.empty(37, device=DEV).exponential_()           # start from a non-zero offset
+    seed, off0 = gen.initial_seed(), gen.get_offset()
+    ref = torch.empty(numel, device=DEV).exponential_()
+    nth, adv = _fill_plan(numel)
+    assert gen.get_offset() - off0 == adv
+    out = torch.empty(numel, device=DEV)
+    H.check(lib.dark_philox_exponential(seed, off0, nth, numel, H.ptr(out), _s()))
+    assert torch.equal(out, ref)
+    from dark_amd.generation_utils import philox_fill_plan
+    gen.set_offset(off0)
+    assert philox_fill_plan(torch.device(DEV), numel) == (seed, off0, nth) and gen.get_offset() - off0 == adv
+
+
+@pytest.mark.parametrize("T,top_p,top_k,mode", [(0.1, 0.9, 0, 2), (0.5, 0.9, 0, 2), (1.0, 0.0, 0, 0), (0.7, 0.0, 20, 1)])
+def test_sample_rows_philox_equals_materialised_noise(lib, T, top_p, top_k, mode):
+    """The sampler fed by the lazy Philox draws == the sampler fed by torch's exponential_ fill of the same state."""
+    H = _hip()
+    g = torch.Generator().manual_seed(5)
+    M, V = 300, 15080
+    logits = (torch.randn(M, V, generator=g) * 0.6).to(DEV)
+    logits[3] *= 8
+    logits[5] = 0.0
+    gen = torch.cuda.default_generators[0]
+    torch.manual_seed(99)
+    seed, off0 = gen.initial_seed(), gen.get_offset()
+    noise = torch.empty(M, V, device=DEV).exponential_()
+    nth, _ = _fill_plan(M * V)
+    c1, x1 = torch.empty(M, device=DEV), torch.empty(M, dtype=torch.long, device=DEV)
+    c2, x2 = torch.empty(M, device=DEV), torch.empty(M, dtype=torch.long, device=DEV)
+    H.check(lib.dark_sample_rows(H.ptr(logits), V, M, V, T, top_p, top_k, mode, H.ptr(noise), V, H.ptr(c1), H.ptr(x1), _s()))
+    H.check(lib.dark_sample_rows_philox(H.ptr(logits), V, M, V, T, top_p, top_k, mode, seed, off0, nth, H.ptr(c2),
+                                        H.ptr(x2), _s()))
+    assert torch.equal(x1, x2) and torch.equal(c1, c2)

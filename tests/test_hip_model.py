@@ -432,3 +432,35 @@ def test_think_sample_matches_reference(mini, golden_meta):
                 lg = otr.mask_logits[i][flat.index(b * mi.shape[1] + j)]
                 assert abs(float(lg[hx[b, j]] - lg[oh[i][b, j]])) <= 1e-5, (c["name"], i, b, j)
     assert exact >= 2, exact                                          # == the reference's goldens end to end
+
+
+def test_lazy_noise_is_invisible(golden_meta):
+    """`lazy_noise=True` (draws computed in the sampler from torch's Philox stream) and `lazy_noise=False` (the
+    [M, V] exponential_ fill the reference makes) give the same sequences and leave the generator at the same
+    offset; checked on the real vocabulary in bf16, fixed-length and variable-length loops."""
+    from dark_amd import DreamModel
+    from dark_amd.generation_expand_utils import DreamGenerationConfig as ExpandConfig
+    kw_cfg = dict(golden_meta["real"], num_hidden_layers=2)
+    cfg = DreamConfig(**kw_cfg)
+    m = DreamModel(cfg)
+    m.load_state_dict(synth.boost_edit_tokens(synth.make_weights(cfg, seed=0), 8.0, 7.0), strict=True)
+    m = m.to(DEV).to(torch.bfloat16)
+    gen = torch.cuda.default_generators[0]
+    ids = synth.make_inputs(48, "ded", seed=3).to(DEV)
+    kw = dict(steps=8, temperature=0.5, alg="entropy", alg_temp=0, top_p=0.9)
+    outs, offs = [], []
+    for lazy in (True, False, True):
+        torch.manual_seed(11)
+        outs.append(m.diffusion_generate_length(ids, generation_config=_gc(45), lazy_noise=lazy, **kw))
+        offs.append(gen.get_offset())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and offs[0] == offs[1] == offs[2]
+    prompts = [p.to(DEV) for p in synth.make_var_inputs(24, "ded", 6, seed=5)]
+    gce = ExpandConfig(mask_token_id=synth.MASK, pad_token_id=synth.END, bos_token_id=synth.BOS, eos_token_id=synth.END,
+                       expand_token_id=synth.EXPAND, delete_token_id=synth.END, max_length=50)
+    outs, offs = [], []
+    for lazy in (True, False):
+        torch.manual_seed(12)
+        outs.append(m.diffusion_generate_batch(prompts, generation_config=gce, temperature=0.5, top_p=0.9, alg_temp=0,
+                                               lazy_noise=lazy))
+        offs.append(gen.get_offset())
+    assert torch.equal(outs[0], outs[1]) and offs[0] == offs[1]
