@@ -325,7 +325,8 @@ __device__ __forceinline__ float philox_exponential(const PhiloxNoise& pn, unsig
   const unsigned int rv = ii == 0 ? raw.x : (ii == 1 ? raw.y : (ii == 2 ? raw.z : raw.w));
   const float v = fmaf((float)rv, ROCRAND_2POW32_INV, ROCRAND_2POW32_INV);  // rocrand uniform_distribution: (0, 1]
   // transformation::exponential with lambda = 1.  The log torch's wheel was built with is the hardware log2 times
-  // ln 2 with a single rounding (found by bit-comparison on 85 M values, tools/philox_check.py; the library logf of
+  // ln 2 with a single rounding (found by bit-comparison on 85 M values; pinned by
+  // tests/test_hip_kernels.py::test_philox_exponential_is_torchs_stream; the library logf of
   // this ROCm release differs from it in the last bit for a third of the arguments).
   const float eps_half = 1.1920928955078125e-07f / 2;
   const float lgv = (float)((double)__builtin_amdgcn_logf(v) * 0.6931471805599453);
