@@ -66,7 +66,12 @@ def main():
     ap.add_argument("--materialise-noise", action="store_true",
                     help="fill the [M,V] categorical noise with torch instead of computing it in the sampler")
     ap.add_argument("--cpu-sample", type=int, default=48, help="sequences in the CPU-oracle sample")
+    ap.add_argument("--workload", default="denoise", choices=["denoise", "expand", "logprob"],
+                    help="denoise = the headline (BASELINE config 2); expand / logprob = the widened paths of SURVEY "
+                         "8f-1 / 8f-3 on one GPU (tools/bench_expand.py, tools/bench_logprob.py) with their CPU-oracle legs")
     args = ap.parse_args()
+    if args.workload != "denoise":
+        return widened(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -183,6 +188,40 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def widened(args):
+    """Single-GPU figures of the widened paths; the CPU legs run here because only bench.py may time oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dark_amd import synth
+    if args.workload == "expand":
+        import bench_expand as T
+        res, w, cfg, prompts = T.run(T.parse([]))
+        if not args.no_cpu_baseline:
+            from oracle import dream_oracle as O  # baseline leg only
+            ocfg = O.OracleConfig(**{k: getattr(cfg, k) for k in O.OracleConfig.__dataclass_fields__})
+            n = 4
+            torch.manual_seed(0)
+            t0 = time.perf_counter()
+            for p in prompts[:n]:
+                O.expand_loop(w, ocfg, p, max_length=50, mask_token_id=synth.MASK, eos_token_id=synth.END,
+                              delete_token_id=synth.END, expand_token_id=synth.EXPAND, temperature=0.1, top_p=0.9,
+                              alg="entropy", alg_temp=0)
+            res["cpu_baseline"] = {"value": round(n / (time.perf_counter() - t0), 3), "unit": "sequences/s",
+                                   "cores": torch.get_num_threads(), "kind": "port", "sample": f"{n} prompts"}
+    else:
+        import bench_logprob as T
+        res, w, cfg, ids, target = T.run(T.parse([]))
+        if not args.no_cpu_baseline:
+            from oracle import dream_oracle as O  # baseline leg only
+            from oracle import grpo_oracle as G
+            ocfg = O.OracleConfig(**{k: getattr(cfg, k) for k in O.OracleConfig.__dataclass_fields__})
+            n = 8
+            t0 = time.perf_counter()
+            G.per_token_logps(w, ocfg, ids[:1, :n], target[:1, :n].long(), [1], synth.MASK)
+            res["cpu_baseline"] = {"value": round(n / (time.perf_counter() - t0), 2), "unit": "completions/s",
+                                   "cores": torch.get_num_threads(), "kind": "port", "sample": f"{n} completions"}
+    print(json.dumps(res), flush=True)
 
 
 def cpu_baseline(cfg, weights, args, synth):

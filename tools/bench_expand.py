@@ -7,8 +7,8 @@ default DARK shape, bf16, random-init weights with the EXPAND / DELETE head rows
 run (a plain random-init model never emits them).  Three legs:
   batched : diffusion_generate_batch over --batch ragged prompts (this repo's reformulation)
   single  : the reference's call pattern, one [1, L] prompt per diffusion_generate call, on the same GPU path
-  cpu     : the oracle (CPU fp32 restatement of the reference loop) on --cpu-sample prompts
-Prints one JSON line.
+Prints one JSON line.  The CPU-oracle leg lives in bench.py (`python bench.py --workload expand`), the only
+benchmark allowed to touch oracle/.
 """
 import argparse
 import json
@@ -22,17 +22,19 @@ sys.path.insert(0, ROOT)
 import torch
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--masks", type=int, default=5)
     ap.add_argument("--single", type=int, default=32)
-    ap.add_argument("--cpu-sample", type=int, default=4)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--gains", type=float, nargs=2, default=(8.0, 7.0))
     ap.add_argument("--no-compact", action="store_true")
-    a = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def run(a):
+    """GPU legs; returns (result dict, weights, config, prompts on the CPU) for a caller that adds a CPU baseline."""
     from dark_amd import DreamConfig, DreamModel, synth
     from dark_amd.generation_expand_utils import DreamGenerationConfig
     dev = torch.device("cuda", 0)
@@ -75,18 +77,11 @@ def main():
            "loop_iterations": steps, "masked_rows_total": int(sum(trace["M"])),
            "single_seq_per_s": round(a.single / dt_s, 2), "single_ms_per_seq": round(dt_s / a.single * 1e3, 2),
            "compaction": not a.no_compact}
-    if a.cpu_sample > 0:
-        from oracle import dream_oracle as O  # baseline leg only
-        ocfg = O.OracleConfig(**{k: getattr(cfg, k) for k in O.OracleConfig.__dataclass_fields__})
-        torch.manual_seed(0)
-        t0 = time.perf_counter()
-        for p in prompts[:a.cpu_sample]:
-            O.expand_loop(w, ocfg, p.cpu(), max_length=50, mask_token_id=synth.MASK, eos_token_id=synth.END,
-                          delete_token_id=synth.END, expand_token_id=synth.EXPAND, temperature=0.1, top_p=0.9,
-                          alg="entropy", alg_temp=0)
-        dt_c = time.perf_counter() - t0
-        res["cpu_oracle_seq_per_s"] = round(a.cpu_sample / dt_c, 3)
-        res["cpu_cores"] = torch.get_num_threads()
+    return res, w, cfg, [p.cpu() for p in prompts]
+
+
+def main():
+    res, _, _, _ = run(parse())
     print(json.dumps(res), flush=True)
 
 

@@ -5,8 +5,8 @@ Workload: `_get_per_token_logps` as the trainer calls it for the old / reference
 (akgr/abduction_model/custom_grpo2.py:681-709): --batch completions of 46 tokens, --iters iterations, i.e.
 3 * iters * batch perturbed sequences through the default DARK shape in bf16, V = 15080.
 Legs: fused (dark_lm_head_logprob: logits never written), unfused (dark_lm_head_rows -> fp32 logits [rows, V] ->
-dark_logprob_from_logits, what a line-by-line port would do), head-only timings of both with HIP events, and the
-CPU oracle on a bounded sample.  Prints one JSON line.
+dark_logprob_from_logits, what a line-by-line port would do), head-only timings of both with HIP events.  Prints one
+JSON line.  The CPU-oracle leg lives in bench.py (`python bench.py --workload logprob`).
 """
 import argparse
 import json
@@ -20,13 +20,15 @@ sys.path.insert(0, ROOT)
 import torch
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--reps", type=int, default=10)
-    ap.add_argument("--cpu-sample", type=int, default=8)
-    a = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def run(a):
     from dark_amd import DreamConfig, DreamModel_length, _hip, grpo_logps, synth
     dev = torch.device("cuda", 0)
     lib = _hip.load()
@@ -44,14 +46,14 @@ def main():
     target = target.view(I, B, N).to(dev)
     seeds = list(range(1, I + 1))
 
-    def run():
+    def call():
         return grpo_logps.get_per_token_logps(model, ids, target, seeds, synth.MASK)
 
-    out = run()
+    out = call()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.reps):
-        out = run()
+        out = call()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.reps
     assert out.shape == (B, I, N) and bool(torch.isfinite(out).all())
@@ -100,15 +102,11 @@ def main():
            "head_rows": M, "head_fused_ms": round(ms_f, 3), "head_unfused_ms": round(ms_u, 3),
            "head_fused_tflops": round(2.0 * M * V * cfg.hidden_size / (ms_f * 1e-3) / 1e12, 1),
            "logits_bytes_avoided": M * V * 4 * 2, "fused_vs_unfused_max_abs_diff": err}
-    if a.cpu_sample > 0:
-        from oracle import dream_oracle as O  # baseline leg only
-        from oracle import grpo_oracle as G
-        ocfg = O.OracleConfig(**{k: getattr(cfg, k) for k in O.OracleConfig.__dataclass_fields__})
-        n = a.cpu_sample
-        t0 = time.perf_counter()
-        G.per_token_logps(w, ocfg, ids[:1, :n].cpu(), target[:1, :n].cpu().long(), [1], synth.MASK)
-        res["cpu_oracle_completions_per_s"] = round(n / (time.perf_counter() - t0), 2)
-        res["cpu_cores"] = torch.get_num_threads()
+    return res, w, cfg, ids.cpu(), target.cpu()
+
+
+def main():
+    res = run(parse())[0]
     print(json.dumps(res), flush=True)
 
 
