@@ -69,7 +69,7 @@ __device__ __forceinline__ int lin_bin(float l, float mx) {
 }
 
 struct Scratch {
-  unsigned long long u64[8];
+  unsigned long long u64[8], u64b[8];
   double f64a[8], f64b[8];
   float f32a[8], f32b[8], f32c[8];
   int i32[8];
@@ -131,6 +131,17 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 #pragma unroll
   for (int w = 0; w < ST / 64; ++w) r += s->u64[w];
   return r;
+}
+
+__device__ __forceinline__ void block_sum2_u64(unsigned long long& a, unsigned long long& b, Scratch* s, int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  __syncthreads();
+  if ((tid & 63) == 0) { s->u64[tid >> 6] = a; s->u64b[tid >> 6] = b; }
+  __syncthreads();
+  a = 0; b = 0;
+#pragma unroll
+  for (int w = 0; w < ST / 64; ++w) { a += s->u64[w]; b += s->u64b[w]; }
 }
 
 // Wave 0 scans `nbin` weight bins in the order first = bin `start`, step `dir` (the descending-logit order)
@@ -218,18 +229,20 @@ __device__ int resolve_candidates(const uint32_t* cand, const unsigned long long
   const uint32_t kj = own ? cand[tid] : 0u;
   const unsigned long long fj = own ? cfx[tid] : 0ull;
   unsigned long long S = A;
-  const int c4 = c & ~3;
-  for (int i = 0; i < c4; i += 4) {  // broadcast LDS reads, independent of each other: issued back to back
-    const uint32_t k0 = cand[i], k1 = cand[i + 1], k2 = cand[i + 2], k3 = cand[i + 3];
-    const unsigned long long f0 = cfx[i], f1 = cfx[i + 1], f2 = cfx[i + 2], f3 = cfx[i + 3];
-    S += (k0 >= kj ? f0 : 0ull) + (k1 >= kj ? f1 : 0ull) + (k2 >= kj ? f2 : 0ull) + (k3 >= kj ? f3 : 0ull);
+  if (tid < ((c + 63) & ~63)) {  // waves that own no candidate skip the O(c) loop
+    const int c4 = c & ~3;
+    for (int i = 0; i < c4; i += 4) {  // broadcast LDS reads, independent of each other: issued back to back
+      const uint32_t k0 = cand[i], k1 = cand[i + 1], k2 = cand[i + 2], k3 = cand[i + 3];
+      const unsigned long long f0 = cfx[i], f1 = cfx[i + 1], f2 = cfx[i + 2], f3 = cfx[i + 3];
+      S += (k0 >= kj ? f0 : 0ull) + (k1 >= kj ? f1 : 0ull) + (k2 >= kj ? f2 : 0ull) + (k3 >= kj ? f3 : 0ull);
+    }
+    for (int i = c4; i < c; ++i) S += cand[i] >= kj ? cfx[i] : 0ull;
   }
-  for (int i = c4; i < c; ++i) S += cand[i] >= kj ? cfx[i] : 0ull;
   const uint32_t best = block_max_u32((own && S > T) ? kj : 0u, s, tid);
   if (best == 0) return 0;
   // mass strictly above tau and the multiplicity of tau, again one candidate per thread
-  const unsigned long long ab = block_sum_u64((own && kj > best) ? fj : 0ull, s, tid);
-  const unsigned long long nt = block_sum_u64((own && kj == best) ? 1ull : 0ull, s, tid);
+  unsigned long long ab = (own && kj > best) ? fj : 0ull, nt = (own && kj == best) ? 1ull : 0ull;
+  block_sum2_u64(ab, nt, s, tid);
   *tau = best;
   *above = A + ab;
   *n_tau = (int)nt;
@@ -249,7 +262,7 @@ __device__ int nucleus_crossing(const float* row, int V, float mx, float top_p, 
   // maximum; when they hold more than top_p of the mass (any peaked row) the crossing is among them
   if (tid == 0) s->ncand = 0;
   __syncthreads();
-  unsigned long long zl = 0;
+  unsigned long long zl = 0, hl = 0;  // row mass and the mass of the elements this thread gathered
   int mine = 0;  // a thread gathers at most 2 of its ~V/512 elements: a flat row overflows after <= 1024 atomics
   for (int i = tid; i < V; i += ST) {
     const float l = row[i];
@@ -258,24 +271,21 @@ __device__ int nucleus_crossing(const float* row, int V, float mx, float top_p, 
     if (l - mx > -HEAD_RANGE) {
       if (mine < 2) {
         const int slot = atomicAdd(&s->ncand, 1);
-        if (slot < CAND_CAP) { cand[slot] = fkey(l); cfx[slot] = fx; cidx[slot] = i; }
+        if (slot < CAND_CAP) { cand[slot] = fkey(l); cfx[slot] = fx; cidx[slot] = i; hl += fx; }
       } else if (mine == 2) {
         atomicAdd(&s->ncand, CAND_CAP + 1);  // poison the count: the head set is incomplete
       }
       ++mine;
     }
   }
-  const unsigned long long Z = block_sum_u64(zl, s, tid);  // (its barriers also publish the candidates)
+  block_sum2_u64(zl, hl, s, tid);  // (its barriers also publish the candidates)
+  const unsigned long long Z = zl;
   const unsigned long long T = (unsigned long long)((double)top_p * (double)Z);  // floor
   *Tout = T;
   int c = s->ncand;
-  if (c <= CAND_CAP) {
-    unsigned long long ml = 0;
-    for (int j = tid; j < c; j += ST) ml += cfx[j];
-    if (block_sum_u64(ml, s, tid) > T) {
-      *head_c = c;
-      return resolve_candidates(cand, cfx, c, 0ull, T, s, tid, tau, above, n_tau);
-    }
+  if (c <= CAND_CAP && hl > T) {  // c <= CAND_CAP: every gathered element has a slot, hl is their total mass
+    *head_c = c;
+    return resolve_candidates(cand, cfx, c, 0ull, T, s, tid, tau, above, n_tau);
   }
   // ---- general path: mass histogram over linear bins, then the elements of the crossing bin
   for (int i = tid; i < NLIN; i += ST) hist[i] = 0;
@@ -360,12 +370,27 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   // 1. temperature (generation_utils.py:60-61) and row max
   float mx = -INFINITY;
   if ((ldl & 3) == 0 && ((uintptr_t)logits & 15) == 0) {
+    // the row is the only HBM traffic of this kernel: a thread's loads are issued back to back, eight at a time
+    // (one at a time, each iteration waits out a full memory latency: 58 % of the wave cycles were spent so)
     const int v4 = V >> 2;
-    for (int i = tid; i < v4; i += ST) {
-      float4 l = *(const float4*)(lr + 4 * i);
-      if (temperature > 0.f) { l.x = l.x / temperature; l.y = l.y / temperature; l.z = l.z / temperature; l.w = l.w / temperature; }
-      *(float4*)(row + 4 * i) = l;
-      mx = fmaxf(fmaxf(mx, fmaxf(l.x, l.y)), fmaxf(l.z, l.w));
+    constexpr int U = 8;
+    for (int base = tid; base < v4; base += ST * U) {
+      float4 buf[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * ST;
+        if (i < v4) buf[u] = *(const float4*)(lr + 4 * i);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * ST;
+        if (i < v4) {
+          float4 l = buf[u];
+          if (temperature > 0.f) { l.x = l.x / temperature; l.y = l.y / temperature; l.z = l.z / temperature; l.w = l.w / temperature; }
+          *(float4*)(row + 4 * i) = l;
+          mx = fmaxf(fmaxf(mx, fmaxf(l.x, l.y)), fmaxf(l.z, l.w));
+        }
+      }
     }
     for (int i = 4 * v4 + tid; i < V; i += ST) {
       float l = lr[i];
