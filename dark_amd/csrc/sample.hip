@@ -250,13 +250,14 @@ __device__ int resolve_candidates(const uint32_t* cand, const unsigned long long
 }
 
 // The nucleus search (see the header).  Returns 1 = found, 0 = no crossing (nothing to filter), -1 = the
-// crossing bin overflows CAND_CAP (caller falls back to the radix select).
+// crossing bin overflows CAND_CAP (caller falls back to the radix select), 2 = (only if defer_small) the head path
+// applies with at most 64 candidates and nothing has been resolved yet: the caller hands the row to list_tail_wave.
 // *head_c: number of gathered head candidates when the head path resolved the crossing (every kept element is
 // then one of cand[0..c) / cidx[0..c)), -1 otherwise.
 __device__ int nucleus_crossing(const float* row, int V, float mx, float top_p, unsigned long long* hist,
                                 uint32_t* cand, unsigned long long* cfx, int* cidx, Scratch* s, int tid,
                                 uint32_t* tau, unsigned long long* above, int* n_tau, unsigned long long* Tout,
-                                int* head_c) {
+                                int* head_c, bool defer_small) {
   *head_c = -1;
   // ---- head path: the pass that sums the masses also gathers the elements within HEAD_RANGE of the
   // maximum; when they hold more than top_p of the mass (any peaked row) the crossing is among them
@@ -285,6 +286,7 @@ __device__ int nucleus_crossing(const float* row, int V, float mx, float top_p, 
   int c = s->ncand;
   if (c <= CAND_CAP && hl > T) {  // c <= CAND_CAP: every gathered element has a slot, hl is their total mass
     *head_c = c;
+    if (defer_small && c <= 64) return 2;
     return resolve_candidates(cand, cfx, c, 0ull, T, s, tid, tau, above, n_tau);
   }
   // ---- general path: mass histogram over linear bins, then the elements of the crossing bin
@@ -348,6 +350,94 @@ __global__ __launch_bounds__(256) void philox_exponential_kernel(PhiloxNoise pn,
                                                                  float* __restrict__ out) {
   const unsigned long long li = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
   if (li < numel) out[li] = philox_exponential(pn, li);
+}
+
+// A peaked row whose head set has at most 64 candidates (what T = 0.1 makes of almost every row) is finished by
+// wave 0 alone: crossing, kept set, softmax, confidence and draw over one candidate per lane, with wave shuffles in
+// place of the block reductions of the general path (each of which costs two barriers and an LDS round trip, ~1 us
+// apiece: a third of the block's lifetime).  The arithmetic is that of the general list mode operation for
+// operation -- the other seven waves would only ever contribute zeros -- so the results are bit-identical.
+__device__ void list_tail_wave(const uint32_t* cand, const unsigned long long* cfx, const int* cidx, int c,
+                               unsigned long long T, float mx, int V, float temperature, int conf_mode,
+                               const float* qr, const PhiloxNoise& pn, unsigned long long q0, int lane,
+                               float* conf_out, int64_t* x0_out) {
+  const bool own = lane < c;
+  const uint32_t kj = own ? cand[lane] : 0u;
+  const unsigned long long fj = own ? cfx[lane] : 0ull;
+  const int my_idx = own ? cidx[lane] : 0;
+  // mass of the candidates not below mine (resolve_candidates with A = 0)
+  unsigned long long S = 0;
+  {
+    const int c4 = c & ~3;
+    for (int i = 0; i < c4; i += 4) {
+      const uint32_t k0 = cand[i], k1 = cand[i + 1], k2 = cand[i + 2], k3 = cand[i + 3];
+      const unsigned long long f0 = cfx[i], f1 = cfx[i + 1], f2 = cfx[i + 2], f3 = cfx[i + 3];
+      S += (k0 >= kj ? f0 : 0ull) + (k1 >= kj ? f1 : 0ull) + (k2 >= kj ? f2 : 0ull) + (k3 >= kj ? f3 : 0ull);
+    }
+    for (int i = c4; i < c; ++i) S += cand[i] >= kj ? cfx[i] : 0ull;
+  }
+  uint32_t tau = (own && S > T) ? kj : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tau = max(tau, (uint32_t)__shfl_xor((int)tau, o, 64));
+  unsigned long long above = (own && kj > tau) ? fj : 0ull, nt = (own && kj == tau) ? 1ull : 0ull;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { above += __shfl_xor(above, o, 64); nt += __shfl_xor(nt, o, 64); }
+  const int n_tau = (int)nt;
+  float my_e = 0.f;
+  // tau != 0: the lowest candidate has S = head mass > T, so some lane qualified
+  const unsigned long long fx = mass_fx(fkey_inv(tau), mx);
+  const unsigned long long t_keep = fx ? (T - above) / fx + 1ull : (unsigned long long)n_tau;
+  if (own) {
+    bool keep = kj > tau;
+    if (kj == tau) {
+      keep = true;
+      if (t_keep < (unsigned long long)n_tau) {  // only the first t_keep (by index) of the equal logits stay
+        unsigned long long rank = 0;
+        for (int i = 0; i < c; ++i) rank += (cand[i] == tau && cidx[i] < my_idx);
+        keep = rank < t_keep;
+      }
+    }
+    if (keep) my_e = exp_neg(fkey_inv(kj) - mx);
+  }
+  const float Zf = (float)wave_sum((double)my_e);
+  double ps = 0.0, ent = 0.0;
+  float t1 = -INFINITY, t2 = -INFINITY, bestp = -INFINITY, my_p = 0.f;
+  int besti = 0x7fffffff;
+  if (my_e > 0.f) {
+    my_p = my_e / Zf;
+    ps = (double)my_p;
+    if (conf_mode == DARK_CONF_NEG_ENTROPY) ent = (double)(my_p * log_pos(my_p + 1e-10f));
+    t1 = my_p;
+    bestp = my_p;
+    besti = my_idx;
+  }
+  const float psum = (float)wave_sum(ps);
+  const float entropy = (float)wave_sum(ent);
+  if (temperature > 0.f) {
+    bestp = -INFINITY;
+    besti = 0x7fffffff;
+    if (my_p > 0.f) {
+      bestp = (my_p / psum) / (pn.nthreads ? philox_exponential(pn, q0 + my_idx) : qr[my_idx]);
+      besti = my_idx;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bestp, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > bestp || (ov == bestp && oi < besti)) { bestp = ov; besti = oi; }
+    const float o1 = __shfl_xor(t1, o, 64), o2 = __shfl_xor(t2, o, 64);
+    const float n1 = fmaxf(t1, o1), n2 = fmaxf(fminf(t1, o1), fmaxf(t2, o2));
+    t1 = n1; t2 = n2;
+  }
+  int bi = besti;
+  if (bi < 0 || bi >= V) bi = 0;
+  if (t2 < 0.f) t2 = 0.f;
+  if (lane == 0) {
+    *conf_out = conf_mode == DARK_CONF_NEG_ENTROPY ? entropy : (conf_mode == DARK_CONF_MARGIN ? t1 - t2 : 0.f);
+    *x0_out = (int64_t)bi;
+  }
+  if (conf_mode == DARK_CONF_PROB && my_e > 0.f && my_idx == bi) *conf_out = my_p;  // after lane 0's store
 }
 
 __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ logits, int64_t ldl, int V,
@@ -418,7 +508,14 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
     unsigned long long above = 0, T = 0;
     int n_tau = 0;
     int head_c = -1;
-    int rc = nucleus_crossing(row, V, mx, top_p, hist, cand, cfx, cidx, s, tid, &tau, &above, &n_tau, &T, &head_c);
+    int rc = nucleus_crossing(row, V, mx, top_p, hist, cand, cfx, cidx, s, tid, &tau, &above, &n_tau, &T, &head_c,
+                              !(top_k > 0 && top_k < V));
+    if (rc == 2) {  // block-uniform: waves 1..7 are done, wave 0 finishes the row without further barriers
+      if (tid < 64)
+        list_tail_wave(cand, cfx, cidx, head_c, T, mx, V, temperature, conf_mode, noise + (int64_t)m * ldn, pn,
+                       (unsigned long long)m * V, tid, conf + m, x0 + m);
+      return;
+    }
     if (rc < 0) rc = select_crossing<true>(row, V, mx, T, hist, cnth, s, tid, &tau, &above, &n_tau) ? 1 : 0;
     if (rc > 0) {
       const unsigned long long fx = mass_fx(fkey_inv(tau), mx);
