@@ -327,9 +327,8 @@ struct PhiloxNoise {
   unsigned long long seed, offset;
   unsigned int nthreads;  // 0: noise comes from memory
 };
-__device__ __forceinline__ float philox_exponential(const PhiloxNoise& pn, unsigned long long li) {
-  const unsigned long long q = li / pn.nthreads;
-  const unsigned int t = (unsigned int)(li - q * pn.nthreads);
+// element li = q * nthreads + t, t < nthreads
+__device__ __forceinline__ float philox_exponential_qt(const PhiloxNoise& pn, unsigned long long q, unsigned int t) {
   rocrand_state_philox4x32_10 st;
   rocrand_init(pn.seed, t, pn.offset + 4ull * (q >> 2), &st);
   const uint4 raw = rocrand4(&st);
@@ -344,6 +343,10 @@ __device__ __forceinline__ float philox_exponential(const PhiloxNoise& pn, unsig
   const float lgv = (float)((double)__builtin_amdgcn_logf(v) * 0.6931471805599453);
   const float lg = v >= 1.0f - eps_half ? -eps_half : lgv;
   return -1.0f / 1.0f * lg;
+}
+__device__ __forceinline__ float philox_exponential(const PhiloxNoise& pn, unsigned long long li) {
+  const unsigned long long q = li / pn.nthreads;
+  return philox_exponential_qt(pn, q, (unsigned int)(li - q * pn.nthreads));
 }
 
 __global__ __launch_bounds__(256) void philox_exponential_kernel(PhiloxNoise pn, unsigned long long numel,
@@ -647,11 +650,22 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
         besti = my_idx;
       }
     } else {
+      // (q, t) of element q0 + i is carried along instead of a 64-bit division per element
+      unsigned long long pq = 0;
+      unsigned int pt = 0;
+      if (pn.nthreads) {
+        pq = (q0 + tid) / pn.nthreads;
+        pt = (unsigned int)(q0 + tid - pq * pn.nthreads);
+      }
       for (int i = tid; i < V; i += ST) {
         const float p = row[i];
         if (p > 0.f) {
-          const float r = (p / psum) / (pn.nthreads ? philox_exponential(pn, q0 + i) : qr[i]);
+          const float r = (p / psum) / (pn.nthreads ? philox_exponential_qt(pn, pq, pt) : qr[i]);
           if (r > bestp) { bestp = r; besti = i; }
+        }
+        if (pn.nthreads) {
+          pt += ST;  // pt < nthreads and ST < 2^31: no wrap
+          while (pt >= pn.nthreads) { pt -= pn.nthreads; ++pq; }
         }
       }
     }
@@ -726,6 +740,7 @@ int launch_sample_philox(const float* logits, int64_t ldl, int M, int V, float t
                  "sample_rows: temperature > 0 needs noise [M,V] or a Philox state");
   const PhiloxNoise pn{seed, offset, nthreads};
   DARK_CHECK_ARG(temperature >= 0.f, "sample_rows: negative temperature");
+  DARK_CHECK_ARG(nthreads <= (1u << 30), "sample_rows: Philox grid of %u threads", nthreads);
   static_assert(NRAD * 12 <= NLIN * 8, "the radix histograms alias the linear histogram");
   const int smem = ((V + 3) & ~3) * 4 + NLIN * 8 + CAND_CAP * 16 + (int)sizeof(Scratch);
   static int attr_smem = 0;
