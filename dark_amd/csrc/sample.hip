@@ -17,7 +17,8 @@
 //   2. the handful of elements of the crossing bin are gathered and resolved exactly (O(c^2/512) per thread).
 // If the crossing bin holds more than CAND_CAP elements (e.g. a flat row), an exact 4 x 8-bit radix select
 // over the order-preserving integer image of the logits takes over; top_k always uses that select with
-// unit weights.  Equal logits keep index order (torch's CPU sort is stable).
+// unit weights.  Inside a run of equal logits the kept ones are the first by index (the reference's unstable
+// torch.sort leaves that order unspecified; oracle.top_p_logits(stable_ties=True) is the same rule).
 //
 // Draw: x0 = argmax_i (p_i / psum) / q_i with q ~ Exp(1) supplied by the caller, which is the ATen
 // multinomial(1) that Categorical(probs).sample() runs; ties -> lowest index (torch argmax).

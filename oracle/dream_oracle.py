@@ -148,9 +148,11 @@ def forward_logits(w, cfg, input_ids, attn_mask=None, position_ids=None) -> torc
 
 
 # --------------------------------------------------------------------------- sampling
-def top_p_logits(logits: torch.Tensor, top_p: float) -> torch.Tensor:
-    """generation_utils.py:37-48."""
-    sorted_logits, sorted_idx = torch.sort(logits, descending=True)
+def top_p_logits(logits: torch.Tensor, top_p: float, stable_ties: bool = False) -> torch.Tensor:
+    """generation_utils.py:37-48.  The reference's `torch.sort` leaves the order inside a run of equal logits
+    unspecified, so which members of a run that straddles the nucleus boundary survive is not pinned by it;
+    `stable_ties=True` fixes index order (the device's rule) for tests that plant such runs."""
+    sorted_logits, sorted_idx = torch.sort(logits, descending=True, stable=stable_ties)
     cum = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1)
     remove = cum > top_p
     remove[..., 1:] = remove[..., :-1].clone()
@@ -185,12 +187,12 @@ def categorical_sample(probs: torch.Tensor, noise: Optional[torch.Tensor] = None
 
 
 def sample_tokens(logits, temperature=0.0, top_p=None, top_k=None, margin_confidence=False,
-                  neg_entropy=False, noise: Optional[torch.Tensor] = None):
+                  neg_entropy=False, noise: Optional[torch.Tensor] = None, stable_ties: bool = False):
     """generation_utils.py:58-90."""
     if temperature > 0:
         logits = logits / temperature
     if top_p is not None and top_p < 1:
-        logits = top_p_logits(logits, top_p)
+        logits = top_p_logits(logits, top_p, stable_ties)
     if top_k is not None:
         logits = top_k_logits(logits, top_k)
     probs = torch.softmax(logits, dim=-1)

@@ -242,6 +242,35 @@ def test_sample_rows_kept_set_matches_top_p(lib):
     assert 0 < int(exp_hit.sum()) < M  # the probe set exercises both outcomes
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("T", [1.0, 0.5, 0.0])
+def test_sample_rows_head_set_sizes(lib, mode, T):
+    """Rows whose mass sits in exactly c elements near the maximum, c around the boundaries between the sampler's
+    paths: <= 64 candidates (wave 0 finishes the row with shuffles), 65..512 (block-wide list mode), > 512 (the head
+    gather overflows: histogram path).  Every third row makes the head elements equal, so that the nucleus boundary
+    falls inside a run of equal logits (only the first few by index survive).  All against oracle.sample_tokens."""
+    g = torch.Generator().manual_seed(21)
+    V = 15080
+    sizes = [1, 2, 3, 17, 63, 64, 65, 66, 128, 301, 511, 512, 513, 701]   # (none with 0.9 * c an integer)
+    rows = []
+    for r, c in enumerate(sizes * 3):
+        l = torch.randn(V, generator=g) * 0.3 - 30.0                      # tail: no mass to speak of
+        idx = torch.randperm(V, generator=g)[:c]
+        l[idx] = (2.0 if r % 3 == 1 else 2.0 + torch.rand(c, generator=g) * 4.0)  # head: within 6 of the maximum
+        if r % 3 == 2 and c > 2:
+            l[idx[: c // 2]] = 5.5                                         # half of the head exactly equal, on top
+        rows.append(l)
+    logits = torch.stack(rows)
+    M = logits.shape[0]
+    noise = torch.empty(M, V).exponential_(1, generator=g) if T > 0 else None
+    margin, negent = mode == _hip().CONF_MARGIN, mode == _hip().CONF_NEG_ENTROPY
+    rc, rx = O.sample_tokens(logits, temperature=T, top_p=0.9, top_k=None, margin_confidence=margin,
+                             neg_entropy=negent, noise=noise, stable_ties=True)
+    conf, x0 = _sample_hip(lib, logits, T, 0.9, None, mode, noise)
+    assert torch.equal(x0, rx), (x0 != rx).nonzero().view(-1).tolist()
+    np.testing.assert_allclose(conf.numpy(), rc.numpy(), rtol=3e-5, atol=1e-6)
+
+
 # --------------------------------------------------------------------------- mask rows + commit
 def _commit_ref(x, mask_id, conf, x0, k):
     """generation_utils.py:522-534 with ties -> lower index."""
