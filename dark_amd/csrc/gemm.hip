@@ -199,12 +199,58 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
     }
   };
 
+  // Residual flavour, 16-byte path: the epilogue is a read-modify-write of the fp32 residual, 24 pieces of 16 bytes
+  // a lane.  Left to the compiler every piece is load -> wait -> add -> store (it cannot tell the rows apart), 24
+  // dependent memory round trips a lane, which at K = 768 outlast the main loop.  Here the old values of the
+  // first two 16-row groups are fetched before the main loop (they ride under the first stage's wait) and those of the
+  // other two in one batch at the top of the epilogue.
+  float* ob = nullptr;
+  float4 old0[2][TNW];
+  auto resid_ok = [&](int mi, int ni) {
+    return m0 + wm * 64 + mi * 16 + frow < M && n0 + wn * WN + 4 * fq + ni * 16 + 4 <= N;
+  };
+  if constexpr (EPI == EPI_RESID) {
+    if (vec_ok) {
+      ob = (float*)out + (int64_t)(m0 + wm * 64 + frow) * ldo + n0 + wn * WN + 4 * fq;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TNW; ++ni)
+          if (resid_ok(mi, ni)) old0[mi][ni] = *(const float4*)(ob + (int64_t)mi * 16 * ldo + ni * 16);
+    }
+  }
+
+  float4 old1[2][TNW];
   stage(0, 0);
   for (int kt = 0; kt < KT; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < KT) stage((kt + 1) & 1, kt + 1);
+    if constexpr (EPI == EPI_RESID) {
+      if (vec_ok && kt == KT - 1) {  // the other two row groups ride under the last compute step
+#pragma unroll
+        for (int mi = 2; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TNW; ++ni)
+            if (resid_ok(mi, ni)) old1[mi - 2][ni] = *(const float4*)(ob + (int64_t)mi * 16 * ldo + ni * 16);
+      }
+    }
     compute(kt & 1);
+  }
+
+  // Residual flavour, 16-byte path: second half of the read-modify-write (see the prefetch above the main loop).
+  if constexpr (EPI == EPI_RESID) {
+    if (vec_ok) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TNW; ++ni)
+          if (resid_ok(mi, ni)) {
+            const float4 p = mi < 2 ? old0[mi & 1][ni] : old1[mi & 1][ni];
+            *(float4*)(ob + (int64_t)mi * 16 * ldo + ni * 16) =
+                make_float4(acc[ni][mi][0] + p.x, acc[ni][mi][1] + p.y, acc[ni][mi][2] + p.z, acc[ni][mi][3] + p.w);
+          }
+    }
   }
 
   // rows beyond M are computed on clamped operands and dropped here; the permlane swaps run in every lane
@@ -292,17 +338,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
       }
     } else {
       if (!row_ok) continue;
+      if constexpr (EPI == EPI_RESID) {
+        if (vec_ok) continue;  // done above, in batches
+      }
       float* orow = (float*)out + mrow * ldo;
 #pragma unroll
       for (int ni = 0; ni < TNW; ++ni) {
         const int c = n0 + wn * WN + ni * 16 + 4 * fq;
-        if (vec_ok && c + 4 <= N) {
-          float4 o = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
-          if constexpr (EPI == EPI_RESID) {
-            const float4 p = *(const float4*)(orow + c);
-            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
-          }
-          *(float4*)(orow + c) = o;
+        if (vec_ok && c + 4 <= N) {  // (EPI_F32; the residual flavour with vec_ok never gets here)
+          *(float4*)(orow + c) = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
