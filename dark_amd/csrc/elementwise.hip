@@ -56,17 +56,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     src = src < 0 ? 0 : (src >= n_src ? n_src - 1 : src);
   }
   const float* xr = x + src * d;
-  float ss = 0.f;
-  for (int c = lane * 4; c < d; c += 256) {
-    const float4 v = *(const float4*)(xr + c);
-    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-  }
-  ss = wave_sum(ss);
-  const float r = 1.0f / sqrtf(ss / (float)d + eps);
   TOut* o = out + (int64_t)row * d;
-  for (int c = lane * 4; c < d; c += 256) {
-    const float4 v = *(const float4*)(xr + c);
-    const float4 g = *(const float4*)(w + c);
+  auto emit = [&](int c, const float4 v, const float4 g, float r) {
     const float y0 = g.x * (v.x * r), y1 = g.y * (v.y * r), y2 = g.z * (v.z * r), y3 = g.w * (v.w * r);
     if constexpr (sizeof(TOut) == 4) {
       *(float4*)(o + c) = make_float4(y0, y1, y2, y3);
@@ -75,7 +66,34 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
       b[0] = (bf16_t)y0; b[1] = (bf16_t)y1; b[2] = (bf16_t)y2; b[3] = (bf16_t)y3;
       *(bf16x4*)(o + c) = b;
     }
+  };
+  if (d <= 1024) {
+    // the row (and the weights) stay in registers between the two passes: one memory round trip per row, not two
+    float4 v[4], g[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int c = lane * 4 + p * 256;
+      if (c < d) { v[p] = *(const float4*)(xr + c); g[p] = *(const float4*)(w + c); }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (lane * 4 + p * 256 < d) ss += v[p].x * v[p].x + v[p].y * v[p].y + v[p].z * v[p].z + v[p].w * v[p].w;
+    ss = wave_sum(ss);
+    const float r = 1.0f / sqrtf(ss / (float)d + eps);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      if (lane * 4 + p * 256 < d) emit(lane * 4 + p * 256, v[p], g[p], r);
+    return;
   }
+  float ss = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 v = *(const float4*)(xr + c);
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float r = 1.0f / sqrtf(ss / (float)d + eps);
+  for (int c = lane * 4; c < d; c += 256) emit(c, *(const float4*)(xr + c), *(const float4*)(w + c), r);
 }
 
 int launch_rmsnorm(int dtype, const float* x, const float* w, void* out, const int32_t* src_rows, int n_src,

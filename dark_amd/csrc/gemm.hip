@@ -220,6 +220,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
     }
   }
 
+  // Bias flavour: the TNW bias pieces of this lane's columns are fetched here, once, and ride under the first
+  // stage's wait; in the epilogue they would be a dependent load in front of every store (24 a lane).
+  float4 b4[TNW];
+  if constexpr (EPI == EPI_BIAS) {
+#pragma unroll
+    for (int ni = 0; ni < TNW; ++ni) {
+      const int c = n0 + wn * WN + ni * 16 + 4 * fq;
+      if (vec_ok && c + 4 <= N) {
+        b4[ni] = *(const float4*)(bias + c);
+      } else {
+        b4[ni].x = c + 0 < N ? bias[c + 0] : 0.f; b4[ni].y = c + 1 < N ? bias[c + 1] : 0.f;
+        b4[ni].z = c + 2 < N ? bias[c + 2] : 0.f; b4[ni].w = c + 3 < N ? bias[c + 3] : 0.f;
+      }
+    }
+  }
+
   float4 old1[2][TNW];
   stage(0, 0);
   for (int kt = 0; kt < KT; ++kt) {
@@ -289,15 +305,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int ni = 2 * np + t;
-          const int c = n0 + wn * WN + ni * 16 + 4 * fq;
-          if (vec_ok && c + 4 <= N) {
-            const float4 b4 = *(const float4*)(bias + c);
-            v[t][0] = acc[ni][mi][0] + b4.x; v[t][1] = acc[ni][mi][1] + b4.y;
-            v[t][2] = acc[ni][mi][2] + b4.z; v[t][3] = acc[ni][mi][3] + b4.w;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[t][e] = acc[ni][mi][e] + (c + e < N ? bias[c + e] : 0.f);
-          }
+          v[t][0] = acc[ni][mi][0] + b4[ni].x; v[t][1] = acc[ni][mi][1] + b4[ni].y;
+          v[t][2] = acc[ni][mi][2] + b4[ni].z; v[t][3] = acc[ni][mi][3] + b4[ni].w;
         }
         store_pair_bf16(v[0], v[1], (bf16_t*)out + mrow * ldo, n0 + wn * WN + np * 32, row_ok ? N : 0, fq, vec_ok);
       }
