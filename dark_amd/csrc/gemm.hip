@@ -183,20 +183,44 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
   auto compute = [&](int buf) {
     const char* as = smem + buf * STAGE + (wm * 64 + frow) * 128;
     const char* ws = smem + buf * STAGE + TILE + (wn * WN + frow) * 128;
+    // All fragment reads of the stage (both 32-wide k halves) are issued before the first MFMA: one exposed LDS
+    // latency per stage instead of one in front of every group of 8 MFMAs (+4 % on qkv and gate/up).  The residual
+    // flavour keeps the compiler's interleaved order: with its prefetched residual pieces the 80 fragment registers
+    // would spill.
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch = ((4 * ks + fq) ^ fsw) << 4;
+        bf16x8 af[4], wf[TNW];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(as + i * 16 * 128 + ch);
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) wf[j] = *(const bf16x8*)(ws + j * 16 * 128 + ch);
+#pragma unroll
+        for (int j = 0; j < TNW; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+      }
+      return;
+    }
+    bf16x8 af[2][4], wf[2][TNW];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ch = ((4 * ks + fq) ^ fsw) << 4;
-      bf16x8 af[4], wf[TNW];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(as + i * 16 * 128 + ch);
+      for (int i = 0; i < 4; ++i) af[ks][i] = *(const bf16x8*)(as + i * 16 * 128 + ch);
 #pragma unroll
-      for (int j = 0; j < TNW; ++j) wf[j] = *(const bf16x8*)(ws + j * 16 * 128 + ch);
+      for (int j = 0; j < TNW; ++j) wf[ks][j] = *(const bf16x8*)(ws + j * 16 * 128 + ch);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int j = 0; j < TNW; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-    }
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
   };
 
   // Residual flavour, 16-byte path: the epilogue is a read-modify-write of the fp32 residual, 24 pieces of 16 bytes
