@@ -68,62 +68,24 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv
   const int64_t ld = 3 * (int64_t)dm;
   const T* base = qkv + (int64_t)b * N * ld + h * HD;
 
-  // ---- stage Q, K (with RoPE) and V.  Every global load of the workgroup is issued before the first one is used
-  // (positions first, they address the cos/sin rows): as loops of load -> use the staging was six dependent memory
-  // round trips a thread, half of the workgroup's lifetime.
-  constexpr int QK_IT = (2 * NP * PC + NTH - 1) / NTH;
-  constexpr int V_IT = (NP * VC + NTH - 1) / NTH;
-  int qt[QK_IT], qp[QK_IT];
-#pragma unroll
-  for (int k = 0; k < QK_IT; ++k) {
-    const int it = tid + k * NTH;
-    const int rem = it % (NP * PC);
-    qt[k] = it < 2 * NP * PC ? rem / PC : NP;  // NP: no item
-    qp[k] = qt[k];
-    if (pos && qt[k] < N) qp[k] = pos[b * N + qt[k]];
-  }
-  raw_t qx1[QK_IT], qx2[QK_IT], vx[V_IT];
-  float qc[QK_IT][VEC], qs[QK_IT][VEC];
-#pragma unroll
-  for (int k = 0; k < QK_IT; ++k) {
-    const int it = tid + k * NTH;
+  // ---- stage Q, K with RoPE
+  for (int it = tid; it < 2 * NP * PC; it += NTH) {
     const int which = it / (NP * PC);
-    const int c = (it % (NP * PC)) % PC;
-    if (qt[k] < N) {
-      const int pp = qp[k] < 0 ? 0 : (qp[k] >= max_pos ? max_pos - 1 : qp[k]);
-      const T* src = base + (int64_t)qt[k] * ld + which * dm + c * VEC;
-      qx1[k] = *(const raw_t*)src;
-      qx2[k] = *(const raw_t*)(src + HALF);
-      const float* cp = cosT + (int64_t)pp * HALF + c * VEC;
-      const float* sp = sinT + (int64_t)pp * HALF + c * VEC;
-#pragma unroll
-      for (int e = 0; e < VEC; e += 4) {
-        const float4 c4 = *(const float4*)(cp + e), s4 = *(const float4*)(sp + e);
-        qc[k][e] = c4.x; qc[k][e + 1] = c4.y; qc[k][e + 2] = c4.z; qc[k][e + 3] = c4.w;
-        qs[k][e] = s4.x; qs[k][e + 1] = s4.y; qs[k][e + 2] = s4.z; qs[k][e + 3] = s4.w;
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < V_IT; ++k) {
-    const int it = tid + k * NTH;
-    const int t = it / VC, c = it - t * VC;
-    if (it < NP * VC && t < N) vx[k] = *(const raw_t*)(base + (int64_t)t * ld + 2 * dm + c * VEC);
-  }
-#pragma unroll
-  for (int k = 0; k < QK_IT; ++k) {
-    const int it = tid + k * NTH;
-    if (it >= 2 * NP * PC) continue;
-    const int which = it / (NP * PC);
-    const int c = (it % (NP * PC)) % PC;
+    const int rem = it - which * (NP * PC);
+    const int t = rem / PC, c = rem - t * PC;
     float o1[VEC], o2[VEC];
-    if (qt[k] < N) {
+    if (t < N) {
+      int p = pos ? pos[b * N + t] : t;
+      p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+      const T* src = base + (int64_t)t * ld + which * dm + c * VEC;
       float x1[VEC], x2[VEC];
-      AttnVec<T>::unpack(qx1[k], x1);
-      AttnVec<T>::unpack(qx2[k], x2);
+      AttnVec<T>::unpack(*(const raw_t*)src, x1);
+      AttnVec<T>::unpack(*(const raw_t*)(src + HALF), x2);
+      const float* cp = cosT + (int64_t)p * HALF + c * VEC;
+      const float* sp = sinT + (int64_t)p * HALF + c * VEC;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float cs = qc[k][e], sn = qs[k][e];
+        const float cs = cp[e], sn = sp[e];
         o1[e] = x1[e] * cs - x2[e] * sn;
         o2[e] = x2[e] * cs + x1[e] * sn;
       }
@@ -131,18 +93,16 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv
 #pragma unroll
       for (int e = 0; e < VEC; ++e) o1[e] = o2[e] = 0.f;
     }
-    T* dst = (which ? Ks : Qs) + qt[k] * LD + c * VEC;
+    T* dst = (which ? Ks : Qs) + t * LD + c * VEC;
     *(raw_t*)dst = AttnVec<T>::pack(o1);
     *(raw_t*)(dst + HALF) = AttnVec<T>::pack(o2);
   }
-#pragma unroll
-  for (int k = 0; k < V_IT; ++k) {
-    const int it = tid + k * NTH;
-    if (it >= NP * VC) continue;
+  // ---- stage V
+  for (int it = tid; it < NP * VC; it += NTH) {
     const int t = it / VC, c = it - t * VC;
     raw_t v;
     if (t < N) {
-      v = vx[k];
+      v = *(const raw_t*)(base + (int64_t)t * ld + 2 * dm + c * VEC);
     } else {
       float z[VEC];
 #pragma unroll

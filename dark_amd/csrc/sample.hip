@@ -64,6 +64,12 @@ __device__ __forceinline__ unsigned long long mass_fx(float l, float mx) {
   if (!(d > -MASS_RANGE)) return 0ull;
   return (unsigned long long)(exp_neg(d) * 1099511627776.0f);  // 2^40
 }
+// the same value without a branch around the exp (d = NaN or -inf: the product is NaN or 0, the select gives 0)
+__device__ __forceinline__ unsigned long long mass_fx_nb(float l, float mx) {
+  const float d = l - mx;
+  const unsigned long long m = (unsigned long long)(exp_neg(fmaxf(d, -MASS_RANGE)) * 1099511627776.0f);
+  return d > -MASS_RANGE ? m : 0ull;
+}
 __device__ __forceinline__ int lin_bin(float l, float mx) {
   const float d = (mx - l) * ((float)(NLIN - 1) / LIN_RANGE);  // monotone non-increasing in l
   return d < (float)(NLIN - 1) ? (int)d : NLIN - 1;            // NaN / inf / huge -> last bin
@@ -266,19 +272,50 @@ __device__ int nucleus_crossing(const float* row, int V, float mx, float top_p, 
   __syncthreads();
   unsigned long long zl = 0, hl = 0;  // row mass and the mass of the elements this thread gathered
   int mine = 0;  // a thread gathers at most 2 of its ~V/512 elements: a flat row overflows after <= 1024 atomics
-  for (int i = tid; i < V; i += ST) {
+  auto gather = [&](float l, unsigned long long fx, int i) {
+    if (mine < 2) {
+      const int slot = atomicAdd(&s->ncand, 1);
+      if (slot < CAND_CAP) { cand[slot] = fkey(l); cfx[slot] = fx; cidx[slot] = i; hl += fx; }
+    } else if (mine == 2) {
+      atomicAdd(&s->ncand, CAND_CAP + 1);  // poison the count: the head set is incomplete
+    }
+    ++mine;
+  };
+  // 16-byte LDS reads, two in flight, masses computed without branches (the sums are integers: which thread adds
+  // which element does not matter); as a loop over single elements every iteration waited out an LDS round trip
+  // and two divergent branches, and this pass was a third of the workgroup's lifetime
+  const int v4 = V >> 2;
+  for (int j0 = tid; j0 < v4; j0 += 2 * ST) {
+    float4 l4[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (j0 + u * ST < v4) l4[u] = *(const float4*)(row + 4 * (j0 + u * ST));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = j0 + u * ST;
+      if (j < v4) {
+        const float le[4] = {l4[u].x, l4[u].y, l4[u].z, l4[u].w};
+        unsigned long long fx[4];
+        bool any_head = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          fx[e] = mass_fx_nb(le[e], mx);
+          zl += fx[e];
+          any_head |= le[e] - mx > -HEAD_RANGE;
+        }
+        if (any_head) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (le[e] - mx > -HEAD_RANGE) gather(le[e], fx[e], 4 * j + e);
+        }
+      }
+    }
+  }
+  for (int i = 4 * v4 + tid; i < V; i += ST) {
     const float l = row[i];
     const unsigned long long fx = mass_fx(l, mx);
     zl += fx;
-    if (l - mx > -HEAD_RANGE) {
-      if (mine < 2) {
-        const int slot = atomicAdd(&s->ncand, 1);
-        if (slot < CAND_CAP) { cand[slot] = fkey(l); cfx[slot] = fx; cidx[slot] = i; hl += fx; }
-      } else if (mine == 2) {
-        atomicAdd(&s->ncand, CAND_CAP + 1);  // poison the count: the head set is incomplete
-      }
-      ++mine;
-    }
+    if (l - mx > -HEAD_RANGE) gather(l, fx, i);
   }
   block_sum2_u64(zl, hl, s, tid);  // (its barriers also publish the candidates)
   const unsigned long long Z = zl;
