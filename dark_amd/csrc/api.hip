@@ -62,11 +62,16 @@ static int forward_hidden(const dark_model_desc* m, const int64_t* ids, const in
   FwdWs w = carve_fwd(m, (size_t)M, (char*)workspace);
   DARK_CHECK_ARG(ws_bytes >= w.total, "forward: workspace %zu < required %zu bytes", ws_bytes, w.total);
 
-  DARK_TRY(launch_embed(m->dtype, ids, m->embed, hidden, M, d, m->vocab, st));
+  if (m->n_layers > 0) {  // embedding + the first layer's input norm in one pass over the gathered rows
+    DARK_CHECK_ARG(m->layers[0].ln1, "layer 0: null weight");
+    DARK_TRY(launch_embed_norm(m->dtype, ids, m->embed, hidden, M, d, m->vocab, m->layers[0].ln1, m->rms_eps, w.xn, st));
+  } else {
+    DARK_TRY(launch_embed(m->dtype, ids, m->embed, hidden, M, d, m->vocab, st));
+  }
   for (int l = 0; l < m->n_layers; ++l) {
     const dark_layer_weights& L = m->layers[l];
     DARK_CHECK_ARG(L.w_qkv && L.b_qkv && L.w_o && L.w_gu && L.w_down && L.ln1 && L.ln2, "layer %d: null weight", l);
-    DARK_TRY(launch_rmsnorm(m->dtype, hidden, L.ln1, w.xn, nullptr, M, M, d, m->rms_eps, st));
+    if (l > 0) DARK_TRY(launch_rmsnorm(m->dtype, hidden, L.ln1, w.xn, nullptr, M, M, d, m->rms_eps, st));
     DARK_TRY(launch_gemm(m->dtype, EPI_BIAS, w.xn, L.w_qkv, L.b_qkv, w.qkv, M, 3 * d, d, 3 * d, st));
     DARK_TRY(launch_attention(m->dtype, w.qkv, m->rope_cos, m->rope_sin, pos, key_mask, w.att, B, N, m->n_heads,
                               m->head_dim, m->max_pos, st));

@@ -115,6 +115,8 @@ int prof_read(double* total_ms, double* total_flops, int* launches);
 int launch_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
                  hipStream_t st);
 // out[m] = w * (x[src(m)] * rsqrt(mean(x^2) + eps)); src_rows nullable (identity), else clamped to [0,n_src)
+int launch_embed_norm(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+                      const float* ln_w, float eps, void* xn, hipStream_t st);
 int launch_rmsnorm(int dtype, const float* x, const float* w, void* out, const int32_t* src_rows, int n_src,
                    int M, int d, float eps, hipStream_t st);
 int launch_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,

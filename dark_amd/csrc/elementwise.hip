@@ -29,6 +29,74 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
   }
 }
 
+// Embedding + the first layer's input RMSNorm in one pass (d <= 1024): the gathered row is already in registers, so
+// xn = weight * row / rms(row) costs no second read of the 4*d-byte fp32 row.  Arithmetic and summation order are
+// rmsnorm_kernel's.
+template <typename TW>
+__global__ __launch_bounds__(256) void embed_norm_kernel(const int64_t* __restrict__ ids, const TW* __restrict__ table,
+                                                         float* __restrict__ out, const float* __restrict__ w,
+                                                         TW* __restrict__ xn, int M, int d, int vocab, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  int64_t id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const TW* src = table + id * d;
+  float4 v[4], g[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int c = lane * 4 + p * 256;
+    if (c < d) {
+      if constexpr (sizeof(TW) == 4) {
+        v[p] = *(const float4*)(src + c);
+      } else {
+        const bf16x4 b = *(const bf16x4*)(src + c);
+        v[p] = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
+      }
+      g[p] = *(const float4*)(w + c);
+      *(float4*)(out + (int64_t)row * d + c) = v[p];
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    if (lane * 4 + p * 256 < d) ss += v[p].x * v[p].x + v[p].y * v[p].y + v[p].z * v[p].z + v[p].w * v[p].w;
+  ss = wave_sum(ss);
+  const float r = 1.0f / sqrtf(ss / (float)d + eps);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int c = lane * 4 + p * 256;
+    if (c < d) {
+      const float y0 = g[p].x * (v[p].x * r), y1 = g[p].y * (v[p].y * r), y2 = g[p].z * (v[p].z * r),
+                  y3 = g[p].w * (v[p].w * r);
+      if constexpr (sizeof(TW) == 4) {
+        *(float4*)(xn + (int64_t)row * d + c) = make_float4(y0, y1, y2, y3);
+      } else {
+        bf16x4 b;
+        b[0] = (bf16_t)y0; b[1] = (bf16_t)y1; b[2] = (bf16_t)y2; b[3] = (bf16_t)y3;
+        *(bf16x4*)(xn + (int64_t)row * d + c) = b;
+      }
+    }
+  }
+}
+
+int launch_embed_norm(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+                      const float* ln_w, float eps, void* xn, hipStream_t st) {
+  if (d > 1024 || d % 4 != 0) {
+    DARK_TRY(launch_embed(dtype, ids, table, out, M, d, vocab, st));
+    return launch_rmsnorm(dtype, out, ln_w, xn, nullptr, M, M, d, eps, st);
+  }
+  DARK_CHECK_ARG(ids && table && out && ln_w && xn, "embed_norm: null pointer");
+  const dim3 grid(cdiv(M, 4)), block(256);
+  if (dtype == DARK_BF16)
+    hipLaunchKernelGGL(embed_norm_kernel<bf16_t>, grid, block, 0, st, ids, (const bf16_t*)table, out, ln_w, (bf16_t*)xn, M,
+                       d, vocab, eps);
+  else
+    hipLaunchKernelGGL(embed_norm_kernel<float>, grid, block, 0, st, ids, (const float*)table, out, ln_w, (float*)xn, M, d,
+                       vocab, eps);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
 int launch_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
                  hipStream_t st) {
   DARK_CHECK_ARG(d % 4 == 0, "embed: d=%d must be a multiple of 4", d);
