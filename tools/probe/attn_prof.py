@@ -1,4 +1,4 @@
-"""Per-phase timestamps of attn_kernel at the bench shape (needs an instrumented build, see make_sample_prof.py for the recipe)."""
+"""Per-phase timestamps of attn_kernel at the bench shape (needs the instrumented build of make_attn_prof.py); phases: staging, kbias + barrier, S = K Q^T, softmax, P V + stores."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -24,8 +24,8 @@ assert raw.dark_dbg_attn_ts(o.ctypes.data_as(ctypes.c_void_p), nb * 8) == 0
 ts = o.reshape(nb, 8).astype(np.int64)
 dd = np.diff(ts[:, :6], axis=1) / 100.0
 print(f"kernel {e0.elapsed_time(e1)*1e3:.1f} us; per-workgroup phases (wave 0), us:")
-for k, n in enumerate(["issue loads+rope+LDS stores", "kbias", "barrier", "S = K Q^T", "softmax", "P V + stores"]):
-    if k < 5: print(f"  {n:30s} {dd[:, k].mean():6.2f}  p10 {np.percentile(dd[:, k],10):6.2f} p90 {np.percentile(dd[:, k],90):6.2f}")
+for k, n in enumerate(["stage Q/K/V (loads, RoPE, LDS stores)", "kbias + barrier", "S = K Q^T", "softmax", "P V + output stores"]):
+    print(f"  {n:38s} {dd[:, k].mean():6.2f}  p10 {np.percentile(dd[:, k],10):6.2f} p90 {np.percentile(dd[:, k],90):6.2f}")
 life = (ts[:, 5] - ts[:, 0]) / 100.0
 span = (ts[:, 5].max() - ts[:, 0].min()) / 100.0
 print(f"  lifetime {life.mean():.2f} us, span {span:.1f} us, concurrency {life.sum()/span:.0f} workgroups")
