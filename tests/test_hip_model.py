@@ -304,6 +304,20 @@ def test_skip_noop_steps_is_invisible(golden_meta):
     assert int(changed.sum()) <= 10  # only the 10 committing steps change x
 
 
+def test_forward_is_deterministic_at_full_size(golden_meta):
+    """The forward at the bench shape (512 x 46 rows: every kernel runs several rounds of workgroups per CU) gives
+    the same bits on repeated calls with other allocations in between -- an uninitialised register or a missing wait
+    shows up here long before it moves a tolerance-based comparison (tools/probe/determinism.py bisects a failure)."""
+    m = _model(golden_meta["real"], False, torch.bfloat16)
+    ids = synth.make_inputs(512, "ded", seed=5).to(DEV)
+    x = torch.nn.functional.pad(ids, (0, 1), value=synth.MASK)
+    ref = m(x).logits.clone()
+    for i in range(3):
+        junk = torch.randn((i + 1) * 1000003, device=DEV)  # moves the caching allocator and the L2 contents
+        assert torch.equal(m(x).logits, ref), f"forward differs on repeat {i}"
+        del junk
+
+
 def test_full_size_properties_bf16(golden_meta):
     """BASELINE config 2 at full size (512 deduction rows, 33 masks, 32 steps, bf16, T=0.1/top_p=0.9): the oracle
     cannot run this in seconds, so check the size-independent invariants of the loop (generation_utils.py:488-540):
