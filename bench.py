@@ -4,6 +4,9 @@
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        # no launcher: starts the N ranks itself (fresh child processes, started
+                                        # before this process touches the GPU) and relays rank 0's JSON line
+    python bench.py --gpus 2 --rehearse # both ranks on cuda:0 over gloo: exercises the N > 1 code on a 1-GPU box
 
 One bench "step" = one pass of the hot path over one batch: BASELINE config 2, the FB15k-237 mixed
 deductive+abductive evaluation batch of 1024 sequences per GPU (512 abduction rows with 11 masks + 512 deduction
@@ -66,6 +69,9 @@ def main():
     ap.add_argument("--materialise-noise", action="store_true",
                     help="fill the [M,V] categorical noise with torch instead of computing it in the sampler")
     ap.add_argument("--cpu-sample", type=int, default=48, help="sequences in the CPU-oracle sample")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on ONE card: every rank uses cuda:0 and the collectives run over gloo (a functional "
+                         "rehearsal of the multi-GPU path, not a measurement)")
     ap.add_argument("--workload", default="denoise", choices=["denoise", "expand", "logprob"],
                     help="denoise = the headline (BASELINE config 2); expand / logprob = the widened paths of SURVEY "
                          "8f-1 / 8f-3 on one GPU (tools/bench_expand.py, tools/bench_logprob.py) with their CPU-oracle legs")
@@ -73,15 +79,20 @@ def main():
     if args.workload != "denoise":
         return widened(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)  # nothing has touched the GPU in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from dark_amd import DreamConfig, DreamGenerationConfig, DreamModel_length, _hip, dispatch, synth
 
@@ -147,12 +158,9 @@ def main():
     dt_skip = time.perf_counter() - t1
 
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, dt_skip], device="cpu" if args.rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-        t = torch.tensor([dt_skip], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_skip = float(t[0])
+        dt, dt_skip = float(t[0]), float(t[1])
     seq_per_s = args.batch * world * args.steps / dt
 
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
@@ -188,6 +196,43 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* as torch.distributed.run would set them), wait for all, relay rank 0's stdout.  The parent never
+    initialises the GPU and never replaces itself: the ranks are children and its exit code is theirs."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # a rank that dies would leave the others waiting in a collective: watch them and stop the rest (by PID)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=5)
+    out = "".join(c for c in chunks if c)
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"rank exit codes {codes}")
 
 
 def widened(args):

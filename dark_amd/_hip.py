@@ -139,6 +139,24 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+def device_guard(device_of):
+    """Decorator: run the function with `device_of(*args, **kwargs)` as the current HIP device.  The library
+    enqueues on the stream it is given and keeps per-device kernel attributes, so the tensors' device must be the
+    current one (dark_hip refuses a stream of another device)."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*args, **kwargs):
+            dev = torch.device(device_of(*args, **kwargs))
+            if dev.type != "cuda":
+                return fn(*args, **kwargs)
+            with torch.cuda.device(dev):
+                return fn(*args, **kwargs)
+        return wrapped
+    return deco
+
+
 def stream_ptr(device: torch.device) -> int:
     """hipStream_t of torch's current stream on `device`, as an integer handle."""
     return torch.cuda.current_stream(device).cuda_stream

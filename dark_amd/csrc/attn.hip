@@ -231,12 +231,8 @@ static int launch_attn_t(const void* qkv, const float* cosT, const float* sinT, 
                          const uint8_t* kmask, void* out, int B, int N, int H, int max_pos, hipStream_t st) {
   constexpr int VEC = AttnVec<T>::VEC;
   constexpr int smem = 3 * NT * 16 * (HD + VEC) * (int)sizeof(T) + NT * 16 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    DARK_CHECK_HIP(hipFuncSetAttribute((const void*)attn_kernel<T, HD, NT, NW>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
-  }
+  static SmemOptIn optin;
+  DARK_TRY(optin.ensure((const void*)attn_kernel<T, HD, NT, NW>, smem, st));
   const float scale = 1.0f / sqrtf((float)HD);
   hipLaunchKernelGGL((attn_kernel<T, HD, NT, NW>), dim3(B * H), dim3(NW * 64), smem, st, (const T*)qkv, cosT, sinT, pos,
                      kmask, (T*)out, N, H, max_pos, scale);

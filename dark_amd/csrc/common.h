@@ -2,6 +2,7 @@
 // Wave = 64 lanes everywhere in this directory.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -54,6 +55,31 @@ void set_error(const char* fmt, ...);
     if (rc__ != DARK_OK) return rc__; \
   } while (0)
 
+// Opt-in to more than 64 KiB of dynamic LDS.  hipFuncSetAttribute applies to the kernel ON THE CURRENT DEVICE, so
+// the "already done" cache is one word per device (atomic: entry points may be called from several host threads).
+// The same call refuses a stream that belongs to another device than the current one: the launch would otherwise
+// run there without the attribute (and without this library's per-device state).
+#define DARK_MAX_DEVICES 64
+struct SmemOptIn {
+  std::atomic<int> have[DARK_MAX_DEVICES] = {};
+  int ensure(const void* fn, int bytes, hipStream_t st) {
+    int dev = 0;
+    DARK_CHECK_HIP(hipGetDevice(&dev));
+    DARK_CHECK_ARG(dev >= 0 && dev < DARK_MAX_DEVICES, "device ordinal %d out of range", dev);
+    if (st != nullptr) {
+      hipDevice_t sdev = dev;
+      DARK_CHECK_HIP(hipStreamGetDevice(st, &sdev));
+      DARK_CHECK_ARG((int)sdev == dev, "stream belongs to device %d but device %d is current (make the model's "
+                     "device current before calling)", (int)sdev, dev);
+    }
+    if (have[dev].load(std::memory_order_acquire) >= bytes) return DARK_OK;
+    DARK_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    int cur = have[dev].load(std::memory_order_relaxed);
+    while (cur < bytes && !have[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+    return DARK_OK;
+  }
+};
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -72,6 +98,15 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// Total order of confidences as torch.topk / torch.sort see them: -inf < finite < +inf < NaN (a NaN counts as the
+// LARGEST value, so a row with NaN confidences still transfers exactly k positions); -0.0 == +0.0 as in a float
+// compare.  Ranking on these keys keeps "ties -> lower index" well defined for every input.
+__device__ __forceinline__ uint32_t order_key(float f) {
+  if (f != f) return 0xffffffffu;
+  const uint32_t u = __float_as_uint(f + 0.0f);  // -0.0 + 0.0 = +0.0
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
 template <typename T> struct ElemTraits;

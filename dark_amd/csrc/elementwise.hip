@@ -12,8 +12,8 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   int64_t id = ids[row];
-  // nn.Embedding raises on out-of-range ids; the host binding validates ids when asked to
-  // (dark_amd/_hip.py), here they are clamped so that no access leaves the table
+  // nn.Embedding raises (device-asserts) on out-of-range ids; here they are clamped so that no access leaves
+  // the table -- nothing validates them on the host, a caller that needs the error checks ids.max() itself
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   const TW* src = table + id * d;
   float* dst = out + (int64_t)row * d;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void commit_kernel(int64_t* __restrict__ x, in
     if (row_index[mid] < key) lo = mid + 1; else hi = mid;
   }
   int m_next = lo;
-  float c[E];
+  uint32_t c[E];  // order_key of the confidence: NaN ranks first, as in torch.topk
   int64_t tok[E];
   bool msk[E];
 #pragma unroll
@@ -294,14 +294,13 @@ __global__ __launch_bounds__(256) void commit_kernel(int64_t* __restrict__ x, in
     const unsigned long long bal = __ballot(is_mask);
     const int rank = __popcll(bal & ((1ull << lane) - 1ull));
     msk[e] = is_mask;
-    c[e] = -INFINITY;
+    c[e] = order_key(-INFINITY);
     tok[e] = mask_id;
     if (is_mask) {
-      c[e] = conf[m_next + rank];
+      c[e] = order_key(conf[m_next + rank]);
       tok[e] = x0[m_next + rank];
     }
-    if (!valid) c[e] = __builtin_nanf("");  // never selected, never counted
-    m_next += __popcll(bal);
+    m_next += __popcll(bal);  // (positions j >= N are never selected and never counted below)
   }
   // rank of every position in (confidence desc, index asc) order
 #pragma unroll
@@ -313,7 +312,7 @@ __global__ __launch_bounds__(256) void commit_kernel(int64_t* __restrict__ x, in
       for (int l2 = 0; l2 < 64; ++l2) {
         const int j2 = e2 * 64 + l2;
         if (j2 >= N) break;
-        const float c2 = __shfl(c[e2], l2, 64);
+        const uint32_t c2 = (uint32_t)__shfl((int)c[e2], l2, 64);
         rank += (c2 > c[e]) || (c2 == c[e] && j2 < j);
       }
     }

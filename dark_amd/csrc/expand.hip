@@ -133,11 +133,11 @@ __global__ __launch_bounds__(64) void expand_commit_edit_kernel(
   // ---- torch.topk(confidence, k) over the masked positions (ties -> lower index), :434-442
   for (int j = lane; j < N; j += 64) {
     if (!was[j]) continue;
-    const float c = cf[j];
+    const uint32_t c = order_key(cf[j]);  // NaN ranks first, as in torch.topk
     int rank = 0;
     for (int j2 = 0; j2 < N; ++j2) {
       if (!was[j2]) continue;
-      const float c2 = cf[j2];
+      const uint32_t c2 = order_key(cf[j2]);
       rank += (c2 > c) || (c2 == c && j2 < j);
     }
     if (rank < k) row[j] = cand[j];

@@ -482,12 +482,8 @@ static int launch_k16(const void* A, const void* W, const float* bias, void* out
   constexpr int smem = 2 * (BM + BNt) * 64 * 2;
   const int tilesM = cdiv(M, BM), tilesN = cdiv(N, BNt);
   const int nwg = tilesM * tilesN;
-  static bool attr_done = false;
-  if (!attr_done) {
-    DARK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_kernel16<EPI, BNt>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
-  }
+  static SmemOptIn optin;
+  DARK_TRY(optin.ensure((const void*)gemm_bf16_kernel16<EPI, BNt>, smem, st));
   hipLaunchKernelGGL((gemm_bf16_kernel16<EPI, BNt>), dim3(nwg), dim3(256), smem, st, (const bf16_t*)A,
                      (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, nwg, vec_ok);
   DARK_CHECK_LAUNCH();

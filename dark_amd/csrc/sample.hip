@@ -544,7 +544,7 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   float my_e = 0.f;  // list mode: exp(l - max) of this thread's candidate if it is kept, else 0
 
   // 2. nucleus filter (generation_utils.py:37-48)
-  if (top_p > 0.f && top_p < 1.f) {
+  if (top_p >= 0.f && top_p < 1.f) {  // 0 keeps the top-1 token alone, like the reference's `cum > 0` (:41-44)
     uint32_t tau = 0;
     unsigned long long above = 0, T = 0;
     int n_tau = 0;
@@ -781,11 +781,8 @@ int launch_sample_philox(const float* logits, int64_t ldl, int M, int V, float t
   DARK_CHECK_ARG(nthreads <= (1u << 30), "sample_rows: Philox grid of %u threads", nthreads);
   static_assert(NRAD * 12 <= NLIN * 8, "the radix histograms alias the linear histogram");
   const int smem = ((V + 3) & ~3) * 4 + NLIN * 8 + CAND_CAP * 16 + (int)sizeof(Scratch);
-  static int attr_smem = 0;
-  if (smem > attr_smem) {
-    DARK_CHECK_HIP(hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_smem = smem;
-  }
+  static SmemOptIn optin;
+  DARK_TRY(optin.ensure((const void*)sample_kernel, smem, st));
   hipLaunchKernelGGL(sample_kernel, dim3(M), dim3(ST), smem, st, logits, ldl, V, temperature, top_p, top_k,
                      conf_mode, noise, ldn, pn, conf, x0);
   DARK_CHECK_LAUNCH();

@@ -37,6 +37,14 @@ def _world(group) -> Tuple[int, int]:
     return 1, 0
 
 
+def _stage(t: torch.Tensor, group) -> torch.Tensor:
+    """The tensor a collective can take: device memory for `nccl` (= RCCL, peer writes over xGMI), host memory
+    for `gloo` (the CPU tests and single-GPU rehearsals, where several ranks share one card)."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        return t.cpu()
+    return t
+
+
 def gather_rows(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     """all_gather of row blocks produced by `shard_bounds` -> the `[total, ...]` tensor on every rank.
     Blocks are padded to the largest block so that one fixed-size collective moves everything."""
@@ -47,10 +55,13 @@ def gather_rows(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     if local.shape[0] != hi - lo:
         raise ValueError(f"rank {rank} holds {local.shape[0]} rows, shard is {hi - lo}")
     width = -(-total // world)
+    device = local.device
+    local = _stage(local, group)
     buf = local.new_zeros((width,) + tuple(local.shape[1:]))
     buf[: hi - lo] = local
     out = local.new_empty((world * width,) + tuple(local.shape[1:]))
     dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
+    out = out.to(device)
     parts = []
     for r in range(world):
         a, b = shard_bounds(total, world, r)
@@ -81,6 +92,7 @@ def global_mask_count(local_count: torch.Tensor, local_batch: int, group=None) -
         return int(local_count), local_batch
     t = torch.stack([local_count.reshape(()).to(torch.int64),
                      torch.tensor(local_batch, dtype=torch.int64, device=local_count.device)])
+    t = _stage(t, group)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return int(t[0]), int(t[1])
 

@@ -151,7 +151,7 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
         noise_fn = kwargs.pop("_noise_fn", None)   # parity tests: (row, step, M_row, V) -> Exp(1) draws
         trace = kwargs.pop("_trace", None)         # parity tests: dict receiving per-step M / conf / x0 / rows
         compact = kwargs.pop("compact_finished", True)
-        self._lazy_noise = bool(kwargs.pop("lazy_noise", True))   # see generation_utils.diffusion_generate
+        lazy_noise = bool(kwargs.pop("lazy_noise", True))   # see generation_utils.diffusion_generate
         # parity tests, teacher forcing: step -> (x [B, max_length], win [B], budget [B]) or None to stop
         state_hook = kwargs.pop("_state_hook", None)
         gc = self._prepare_generation_config(generation_config, **kwargs)
@@ -193,14 +193,22 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
                 f" is on {self.device.type}. You may experience unexpected behaviors or slower generation.",
                 UserWarning)
         return self._sample(packed, prefixes, n_masks, gc, _single=single, _noise_fn=noise_fn, _trace=trace,
-                            _compact=compact, _state_hook=state_hook)
+                            _compact=compact, _state_hook=state_hook, _lazy_noise=lazy_noise)
 
     # ------------------------------------------------------------------ the loop
     def _sample(self, input_ids, prefix_len, start_gen_len, generation_config, _single: Optional[bool] = None,
                 _noise_fn: Optional[Callable] = None, _trace: Optional[dict] = None, _compact: bool = True,
-                _state_hook: Optional[Callable] = None):
+                _state_hook: Optional[Callable] = None, _lazy_noise: bool = True):
         """generation_expand_utils.py:358-503 for every row at once.  `input_ids`: a `[1, L]` tensor with scalar
         `prefix_len` / `start_gen_len` (the reference signature) or lists of them."""
+        if self.device.type != "cuda":
+            raise RuntimeError("dark_amd runs on a HIP device only: move the model with .to('cuda')")
+        with torch.cuda.device(self.device):  # the library launches on the CURRENT device's stream
+            return self._sample_impl(input_ids, prefix_len, start_gen_len, generation_config, _single, _noise_fn,
+                                     _trace, _compact, _state_hook, _lazy_noise)
+
+    def _sample_impl(self, input_ids, prefix_len, start_gen_len, generation_config, _single, _noise_fn, _trace,
+                     _compact, _state_hook, _lazy_noise):
         gc = generation_config
         if isinstance(input_ids, torch.Tensor):   # the reference signature: one [1, L] prompt
             L = int(input_ids.shape[1])
@@ -216,7 +224,7 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
         if alg not in _CONF_MODE:
             raise RuntimeError(f"Unknown alg: {alg}")
         temperature = float(gc.temperature)
-        top_p_f = float(gc.top_p) if (gc.top_p is not None and gc.top_p < 1) else 0.0
+        top_p_f = max(float(gc.top_p), 0.0) if (gc.top_p is not None and gc.top_p < 1) else -1.0  # < 0 = off
         top_k_i = int(min(gc.top_k, self.config.vocab_size)) if gc.top_k is not None else 0
         k = int(gc.number_transfer_tokens)
         N = int(gc.max_length)
@@ -305,7 +313,7 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
                     noise = torch.cat([_noise_fn(origin_host[b_live], i, m_b, V).to(torch.float32)
                                        for b_live, m_b in per.items()]).to(device).contiguous()
                     assert noise.shape == (M, V)
-                elif getattr(self, "_lazy_noise", False):
+                elif _lazy_noise:
                     philox = _fixed.philox_fill_plan(device, M * V)
                 else:
                     noise = torch.empty((M, V), device=device, dtype=torch.float32).exponential_()

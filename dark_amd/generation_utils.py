@@ -127,6 +127,19 @@ def philox_fill_plan(device: torch.device, numel: int) -> Tuple[int, int, int]:
     return seed, offset, nthreads
 
 
+@dataclass
+class _LoopCtx:
+    """Per-call options of one ``diffusion_generate`` (never stored on the model: calls on different threads or
+    nested calls from hooks do not see each other's settings)."""
+    skip_noop: bool = True          # reuse the hidden states of an unchanged x on steps that commit nothing
+    lazy_noise: bool = True         # Exp(1) draws evaluated inside the sampler from torch's Philox stream
+    noise_fn: Optional[Callable] = None      # parity tests: inject the Exp(1) draws, (step, M, V) -> [M, V]
+    rand_fn: Optional[Callable] = None       # parity tests: inject alg='origin' uniforms, (step, M) -> [M]
+    state_hook: Optional[Callable] = None    # parity tests: teacher forcing, (step, x) -> x
+    count_reduce: Optional[Callable] = None  # dispatch.generate_sharded(exact_ragged_k=True)
+    trace: Optional[dict] = None             # parity tests: receives per-step k / conf / x0
+
+
 class DreamGenerationMixin:
     """Drop-in for the reference mixin; the model class supplies the ``_hip_*`` launch helpers."""
 
@@ -199,20 +212,18 @@ class DreamGenerationMixin:
         generation_config = self._prepare_generation_config(generation_config, **kwargs)
         tokens_hook = kwargs.pop("generation_tokens_hook_func", None)
         logits_hook = kwargs.pop("generation_logits_hook_func", None)
-        noise_fn = kwargs.pop("_noise_fn", None)  # parity tests: inject the Exp(1) draws
-        self._rand_fn = kwargs.pop("_rand_fn", None)  # parity tests: inject alg='origin' uniforms
-        trace = kwargs.pop("_trace", None)        # parity tests: dict receiving per-step k / conf / x0
-        self._state_hook = kwargs.pop("_state_hook", None)  # parity tests: teacher forcing, (step, x) -> x
-        # dispatch.generate_sharded(exact_ragged_k=True): (count tensor, B_local) -> (global masks, global rows)
-        self._count_reduce = kwargs.pop("_count_reduce", None)
         # Steps whose transfer count is 0 leave x untouched (with 11 masks and 32/64 steps the reference's own
         # schedule makes 22/54 of them): their only observable effect is the RNG draw.  With skip_noop_steps the
         # loop keeps that draw and reuses the hidden states of the unchanged x instead of recomputing them.
-        self._skip_noop = bool(kwargs.pop("skip_noop_steps", True))
-        # The Exp(1) draws of Categorical.sample() are computed inside the sampler from torch's Philox stream (same
-        # generator state, same values as the [M, V] `exponential_` fill the reference makes) instead of being
-        # written to and read back from HBM; False materialises them with torch.
-        self._lazy_noise = bool(kwargs.pop("lazy_noise", True))
+        # lazy_noise: the Exp(1) draws of Categorical.sample() are computed inside the sampler from torch's Philox
+        # stream (same generator state, same values as the [M, V] `exponential_` fill the reference makes) instead
+        # of being written to and read back from HBM; False materialises them with torch.
+        # _count_reduce (dispatch.generate_sharded): (count tensor, B_local) -> (global masks, global rows)
+        ctx = _LoopCtx(skip_noop=bool(kwargs.pop("skip_noop_steps", True)),
+                       lazy_noise=bool(kwargs.pop("lazy_noise", True)),
+                       noise_fn=kwargs.pop("_noise_fn", None), rand_fn=kwargs.pop("_rand_fn", None),
+                       state_hook=kwargs.pop("_state_hook", None), count_reduce=kwargs.pop("_count_reduce", None),
+                       trace=kwargs.pop("_trace", None))
 
         assert inputs is not None
         input_ids = inputs
@@ -243,14 +254,22 @@ class DreamGenerationMixin:
             expand_size=generation_config.num_return_sequences, input_ids=input_ids, attention_mask=attention_mask)
         return self._sample_fixed(input_ids, attention_mask=attention_mask, generation_config=generation_config,
                                   generation_tokens_hook_func=tokens_hook, generation_logits_hook_func=logits_hook,
-                                  noise_fn=noise_fn, trace=trace)
+                                  ctx=ctx)
 
     # ------------------------------------------------------------------ the loop
     def _sample_fixed(self, input_ids: torch.LongTensor, attention_mask: Optional[torch.Tensor],
                       generation_config: DreamGenerationConfig, generation_tokens_hook_func=None,
-                      generation_logits_hook_func=None, noise_fn: Optional[Callable] = None,
-                      trace: Optional[dict] = None) -> Union[DreamModelOutput, torch.LongTensor]:
+                      generation_logits_hook_func=None, ctx: Optional[_LoopCtx] = None
+                      ) -> Union[DreamModelOutput, torch.LongTensor]:
         """generation_utils.py:435-548 (and its copy generation_expand_utils.py:572-672)."""
+        if self.device.type != "cuda":
+            raise RuntimeError("dark_amd runs on a HIP device only: move the model with .to('cuda')")
+        with torch.cuda.device(self.device):  # the library launches on the CURRENT device's stream
+            return self._sample_fixed_impl(input_ids, attention_mask, generation_config, generation_tokens_hook_func,
+                                           generation_logits_hook_func, ctx or _LoopCtx())
+
+    def _sample_fixed_impl(self, input_ids, attention_mask, generation_config, generation_tokens_hook_func,
+                           generation_logits_hook_func, ctx: _LoopCtx):
         gc = generation_config
         steps, eps, alg, alg_temp = gc.steps, gc.eps, gc.alg, gc.alg_temp
         temperature, top_p, top_k = gc.temperature, gc.top_p, gc.top_k
@@ -262,9 +281,8 @@ class DreamGenerationMixin:
         if alg not in ("origin", "maskgit_plus", "topk_margin", "entropy"):
             raise RuntimeError(f"Unknown alg: {alg}")
         device = self.device
-        if device.type != "cuda":
-            raise RuntimeError("dark_amd runs on a HIP device only: move the model with .to('cuda')")
-        input_ids = input_ids.to(device)
+        # the kernels read int64 ids; nn.Embedding in the reference also takes int32 (modeling_dream_length.py:665)
+        input_ids = input_ids.to(device=device, dtype=torch.int64)
 
         x = F.pad(input_ids, (0, gc.max_length - input_ids.shape[1]), value=mask_token_id).contiguous()
         B, N = x.shape
@@ -281,7 +299,8 @@ class DreamGenerationMixin:
         tokens_hook = generation_tokens_hook_func or (lambda step, x, logits: x)
         logits_hook = generation_logits_hook_func or (lambda step, x, logits: logits)
         fast = default_hooks and alg != "origin" and (alg_temp is None or alg_temp == 0) and not think
-        top_p_f = float(top_p) if (top_p is not None and top_p < 1) else 0.0
+        # the reference filters iff `top_p is not None and top_p < 1` (:62): 0 keeps the top-1 token only; < 0 = off
+        top_p_f = max(float(top_p), 0.0) if (top_p is not None and top_p < 1) else -1.0
         top_k_i = int(min(top_k, self.config.vocab_size)) if top_k is not None else 0
 
         x = tokens_hook(None, x, None).contiguous()
@@ -292,20 +311,22 @@ class DreamGenerationMixin:
             last = i == steps - 1
             if fast:
                 self._step_fast(st, x, pos, key_mask, mask_token_id, temperature, top_p_f, top_k_i, _CONF_MODE[alg],
-                                t, s, last, i, noise_fn, trace)
+                                t, s, last, i, ctx)
             else:
                 # think_sample steps (generation_utils.py:490-491, :411-432): `check_and_select` forwards 4 identical
                 # copies of every row with arange positions (`calculate_results`, :369-372), resamples them twice and
                 # returns the first-pass logits of the copy whose resampled observation side is closest -- the
                 # copies' logits are identical, so what reaches the sampler is the forward with arange positions.
-                # That forward is what runs here; the two discarded categorical draws are not consumed from the
-                # RNG stream, and the IndexError the reference raises when row 0 holds no SEP is not reproduced.
+                # That forward is what runs here; `_think_side_effects` reproduces what else the call does: the
+                # generator advance of its two discarded categorical draws and its IndexError.
                 think_step = think and i % gc.think_sample_interval == 0
+                if think_step:
+                    self._think_side_effects(x, mask_token_id, gc.sep_token_id, ctx)
                 x = self._step_general(st, x, None if think_step else pos, key_mask, mask_token_id, temperature,
                                        top_p_f, top_k_i, alg, alg_temp, t, s, last, i, tokens_hook, logits_hook,
-                                       noise_fn, trace).contiguous()
-            if getattr(self, "_state_hook", None) is not None:
-                x.copy_(self._state_hook(i, x).to(x.device))
+                                       ctx).contiguous()
+            if ctx.state_hook is not None:
+                x.copy_(ctx.state_hook(i, x).to(x.device))
                 st.hidden_valid = False
             if histories is not None:
                 histories.append(x.clone())
@@ -313,6 +334,24 @@ class DreamGenerationMixin:
         if gc.return_dict_in_generate:
             return DreamModelOutput(sequences=x, history=histories)
         return x
+
+    def _think_side_effects(self, x: torch.Tensor, mask_id: int, sep_id, ctx: _LoopCtx) -> None:
+        """What `check_and_select` (generation_utils.py:411-432) does besides returning logits.
+        * `sep_positions[0]` (:418-419) raises IndexError when row 0 holds no SEP.  The reference searches row 0
+          AFTER its masked positions were filled with the first think draw; here the unmasked positions of row 0 are
+          searched, so the two differ only if that discarded draw itself produced a SEP token in row 0.
+        * `calculate_results` runs `Categorical(probs=softmax(logits[4B, N, V])).sample()` twice with its default
+          temperature 1.0 (:374-377, :414, :426): two `exponential_` fills of [4*B*N, V] each.  The samples never
+          reach the result, but the fills advance the global generator; the same Philox offsets are reserved here
+          (nothing is generated).  fp32 models only: in bf16 the reference's Categorical fails its simplex check on
+          a V-way softmax, falls into the bare `except` and draws nothing."""
+        row0 = x[0]
+        if sep_id is None or not bool(((row0 == sep_id) & (row0 != mask_id)).any()):
+            raise IndexError("index 0 is out of bounds for dimension 0 with size 0")  # sep_positions[0], :419
+        if ctx.noise_fn is None and self.dtype == torch.float32:
+            B, N = x.shape
+            for _ in range(2):
+                philox_fill_plan(x.device, 4 * B * N * self.config.vocab_size)
 
     def _draw_noise(self, step: int, M: int, V: int, device, noise_fn) -> torch.Tensor:
         """The ``q = empty_like(probs).exponential_()`` of ATen multinomial, drawn from torch's device
@@ -324,17 +363,18 @@ class DreamGenerationMixin:
         return torch.empty((M, V), device=device, dtype=torch.float32).exponential_()
 
     def _step_fast(self, st, x, pos, key_mask, mask_id, temperature, top_p, top_k, conf_mode, t, s, last, step,
-                   noise_fn, trace) -> None:
+                   ctx: _LoopCtx) -> None:
         """One iteration of generation_utils.py:488-540 for the confidence algorithms, fully on device."""
         B, N = x.shape
         V = self.config.vocab_size
-        skip = getattr(self, "_skip_noop", False) and trace is None
+        noise_fn, trace = ctx.noise_fn, ctx.trace
+        skip = ctx.skip_noop and trace is None
         if not (skip and st.hidden_valid):
             st.mask_rows(x, mask_id)              # row_index / src_rows / count, then async count read-back
             st.forward_hidden(x, pos, key_mask)   # enqueued before the host waits for the count
             st.hidden_valid = True                # ... for as long as x does not change
         M = st.wait_count()
-        Mg, Bg = (M, B) if getattr(self, '_count_reduce', None) is None else self._count_reduce(st.count[:1], B)
+        Mg, Bg = (M, B) if ctx.count_reduce is None else ctx.count_reduce(st.count[:1], B)
         k = transfer_count(Mg, Bg, t, s, last)
         if trace is not None:
             trace.setdefault("k", []).append(k)
@@ -343,7 +383,7 @@ class DreamGenerationMixin:
             return
         noise = philox = None
         if temperature > 0:
-            if noise_fn is None and getattr(self, "_lazy_noise", False):
+            if noise_fn is None and ctx.lazy_noise:
                 philox = philox_fill_plan(x.device, M * V)
             else:
                 noise = self._draw_noise(step, M, V, x.device, noise_fn)
@@ -358,11 +398,12 @@ class DreamGenerationMixin:
             st.hidden_valid = False
 
     def _step_general(self, st, x, pos, key_mask, mask_id, temperature, top_p, top_k, alg, alg_temp, t, s, last, step,
-                      tokens_hook, logits_hook, noise_fn, trace) -> torch.Tensor:
+                      tokens_hook, logits_hook, ctx: _LoopCtx) -> torch.Tensor:
         """Same iteration with materialised ``[B,N,V]`` logits for hooks, ``alg='origin'`` and
         ``alg_temp > 0`` (host-sequenced tensor ops around the same HIP entry points)."""
         B, N = x.shape
         V = self.config.vocab_size
+        noise_fn, trace = ctx.noise_fn, ctx.trace
         mask_index = x == mask_id
         st.hidden_valid = False
         st.forward_hidden(x, pos, key_mask)
@@ -374,8 +415,7 @@ class DreamGenerationMixin:
         if alg == "origin":
             p_transfer = 1 - s / t if not last else 1
             x0 = torch.zeros(M, device=x.device, dtype=torch.long) + mask_id
-            u = torch.rand(M, device=x.device) if getattr(self, "_rand_fn", None) is None \
-                else self._rand_fn(step, M).to(x.device)
+            u = torch.rand(M, device=x.device) if ctx.rand_fn is None else ctx.rand_fn(step, M).to(x.device)
             transfer = u < p_transfer.to(x.device) if isinstance(p_transfer, torch.Tensor) else u < p_transfer
             sel = mask_logits[transfer].contiguous()
             if sel.shape[0] > 0:
@@ -390,7 +430,7 @@ class DreamGenerationMixin:
             else:
                 confidence = torch.empty(0, device=x.device)
                 x0 = torch.empty(0, device=x.device, dtype=torch.long)
-            Mg, Bg = (M, B) if getattr(self, '_count_reduce', None) is None else self._count_reduce(mask_index.sum().reshape(1), B)
+            Mg, Bg = (M, B) if ctx.count_reduce is None else ctx.count_reduce(mask_index.sum().reshape(1), B)
             k = transfer_count(Mg, Bg, t, s, last)
             if trace is not None:
                 trace.setdefault("k", []).append(k)

@@ -38,6 +38,7 @@ def _u8(t: torch.Tensor) -> torch.Tensor:
     return (t != 0).to(torch.uint8).contiguous()
 
 
+@_hip.device_guard(lambda batch, *a, **k: batch.device)
 def forward_process(batch: torch.Tensor, mask_target: torch.Tensor, mask_id: int, seed: Optional[int] = None,
                     accumulate: bool = False, gradient_accumulation_steps: int = 1,
                     _rand_fn: Optional[Callable[[int, int], torch.Tensor]] = None):
@@ -74,6 +75,7 @@ def _shift_rows(model, S: int, N: int) -> torch.Tensor:
     return src
 
 
+@_hip.device_guard(lambda model, *a, **k: model.device)
 def get_logits(model, batch: torch.Tensor) -> torch.Tensor:
     """custom_grpo2.py:409-418: `model(batch).logits` shifted right by one position, fp32 [S, N, V] (materialised:
     use `get_per_token_logps` to avoid that)."""
@@ -85,6 +87,7 @@ def get_logits(model, batch: torch.Tensor) -> torch.Tensor:
     return st.head_rows(_shift_rows(model, S, N), S * N).view(S, N, model.config.vocab_size).clone()
 
 
+@_hip.device_guard(lambda logits, *a, **k: logits.device)
 def selective_log_softmax(logits: torch.Tensor, index: torch.Tensor, weights: Optional[torch.Tensor] = None,
                           mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """custom_grpo2.py:89-161 on materialised logits [I*3*B, N, V] (any float dtype; computed in fp32)."""
@@ -108,6 +111,7 @@ def selective_log_softmax(logits: torch.Tensor, index: torch.Tensor, weights: Op
     return out
 
 
+@_hip.device_guard(lambda model, *a, **k: model.device)
 def get_per_token_logps(model, input_ids: torch.Tensor, mask_attention: torch.Tensor, mask_seeds: Sequence[int],
                         mask_token_id: int, gradient_accumulation_steps: int = 1,
                         _rand_fn: Optional[Callable[[int, int, int], torch.Tensor]] = None) -> torch.Tensor:

@@ -16,6 +16,7 @@ from . import _hip
 MODES = {"unify": 0, "sft_abd": 1, "sft_ded": 2}
 
 
+@_hip.device_guard(lambda query_ids, *a, **k: query_ids.device)
 def build_inputs(query_ids: torch.Tensor, observation_ids: torch.Tensor, model_type: str, bos_token_id: int,
                  sep_token_id: int, eos_token_id: int, mask_token_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """(input_ids [B, Q+A+3] int64, need_to_mask [B, Q+A+3] float32) as akgr/tokenizer.py:318-338 returns them."""
@@ -35,6 +36,7 @@ def build_inputs(query_ids: torch.Tensor, observation_ids: torch.Tensor, model_t
     return ids, need
 
 
+@_hip.device_guard(lambda test_ids, *a, **k: test_ids.device)
 def split_strip(test_ids: torch.Tensor, sep_token_id: int, special_ids: Iterable[int]):
     """main.py:409-421 at the id level.  Returns (sep_pos, left [B,N], left_len [B], right [B,N], right_len [B]):
     the kept ids of `test_ids[:, :sep_pos]` / `test_ids[:, sep_pos+1:]`, padded with -1."""

@@ -375,7 +375,14 @@ class DreamModel_length(DreamGenerationMixin, nn.Module):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")  # :654-655
         if kwargs.get("inputs_embeds") is not None or kwargs.get("labels") is not None:
             raise NotImplementedError("inputs_embeds / labels are outside the inference hot path")
-        x = input_ids.to(self.device).contiguous()
+        if self.device.type != "cuda":
+            raise RuntimeError("dark_amd runs on a HIP device only: move the model with .to('cuda')")
+        with torch.cuda.device(self.device):  # the library launches on the CURRENT device's stream
+            return self._forward_impl(input_ids, attention_mask, position_ids, num_logits_to_keep)
+
+    def _forward_impl(self, input_ids, attention_mask, position_ids, num_logits_to_keep) -> MaskedLMOutput:
+        # the kernels read int64 ids; nn.Embedding in the reference also takes int32 (:665)
+        x = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         B, N = x.shape
         key_mask = None
         if isinstance(attention_mask, torch.Tensor):

@@ -112,7 +112,8 @@ int dark_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* row
  *   logits [M, ldl] fp32 (read-only), V columns used
  *   temperature: 0 => greedy (probs.max); > 0 => x0 = argmax(p_norm / noise), the ATen
  *                multinomial(1) that Categorical.sample() runs (:70)
- *   top_p: nucleus threshold, applied iff 0 < top_p < 1;  top_k: applied iff > 0
+ *   top_p: nucleus threshold, applied iff 0 <= top_p < 1 (0 keeps the top-1 token; pass a negative value for
+ *          `top_p=None`);  top_k: applied iff > 0
  *   noise [M, ldn] fp32 Exp(1) draws (`empty_like(probs).exponential_()`), required iff temperature > 0
  *   conf [M] fp32 OUT, x0 [M] int64 OUT */
 int dark_sample_rows(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p,

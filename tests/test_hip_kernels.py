@@ -171,7 +171,7 @@ def _sample_hip(lib, logits, T, top_p, top_k, mode, noise):
     x0 = torch.zeros(M, dtype=torch.long, device=DEV)
     ld = logits.to(DEV).contiguous()
     nd = noise.to(DEV).contiguous() if noise is not None else None
-    H.check(lib.dark_sample_rows(H.ptr(ld), V, M, V, float(T), float(top_p or 0.0), int(top_k or 0), mode, H.ptr(nd),
+    H.check(lib.dark_sample_rows(H.ptr(ld), V, M, V, float(T), float(-1.0 if top_p is None else top_p), int(top_k or 0), mode, H.ptr(nd),
                                  V if nd is not None else 0, H.ptr(conf), H.ptr(x0), _s()))
     torch.cuda.synchronize()
     return conf.cpu(), x0.cpu()
@@ -317,6 +317,54 @@ def test_mask_rows_and_commit(lib, B, N, k):
     assert torch.equal(xd.cpu(), _commit_ref(x, mask_id, conf, x0, k))
 
 
+def test_commit_nan_confidence_counts_as_largest(lib):
+    """torch.topk orders NaN as the largest value and still selects exactly k (generation_utils.py:526): a NaN
+    confidence must be transferred first, not `every NaN regardless of k`; -0.0 ties with +0.0 (lower index wins)."""
+    H = _hip()
+    mask_id, B, N = 6, 2, 46
+    x = torch.full((B, N), 9, dtype=torch.long)
+    x[0, [3, 7, 11, 20, 30]] = mask_id
+    x[1, [1, 2, 5]] = mask_id
+    conf = torch.tensor([0.5, float("nan"), 0.9, float("nan"), float("nan"), 0.0, -0.0, -1.0])
+    x0 = torch.arange(100, 108)
+    for k in (1, 2, 4):
+        xd = x.to(DEV)
+        ri = torch.zeros(B * N, dtype=torch.int32, device=DEV)
+        sr = torch.zeros(B * N, dtype=torch.int32, device=DEV)
+        cnt = torch.zeros(4, dtype=torch.int32, device=DEV)
+        H.check(lib.dark_mask_rows(H.ptr(xd), B, N, mask_id, H.ptr(ri), H.ptr(sr), H.ptr(cnt), _s()))
+        cd, x0d = conf.to(DEV), x0.to(DEV)  # kept alive across the asynchronous launch
+        H.check(lib.dark_commit_topk(H.ptr(xd), B, N, mask_id, H.ptr(ri), 8, H.ptr(cd), H.ptr(x0d), k, _s()))
+        torch.cuda.synchronize()
+        got = xd.cpu()
+        # row 0: NaNs at masked slots 1, 3, 4 (positions 7, 20, 30) go first in index order, then 0.9, then 0.5
+        order0 = [7, 20, 30, 11, 3]
+        exp = x.clone()
+        for j in order0[:k]:
+            exp[0, j] = x0[[3, 7, 11, 20, 30].index(j)]
+        # row 1: 0.0 (pos 1) ties with -0.0 (pos 2): the lower index first; -1.0 last; k = 4 re-masks position 0
+        order1 = [1, 2, 5]
+        for j in order1[:k]:
+            exp[1, j] = x0[5 + order1.index(j)]
+        if k == 4:
+            exp[1, 0] = mask_id
+        assert torch.equal(got, exp), (k, got[0].tolist(), got[1].tolist())
+
+
+def test_top_p_zero_keeps_only_the_top_token(lib):
+    """`top_p=0.0` is a live filter in the reference (`top_p is not None and top_p < 1`, generation_utils.py:62):
+    `cum > 0` removes everything after the first sorted token, so sampling is greedy whatever the noise says."""
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(64, 15080, generator=g)
+    noise = torch.empty_like(logits).exponential_(1, generator=g)
+    rc, rx = O.sample_tokens(logits, temperature=0.7, top_p=0.0, neg_entropy=True, noise=noise)
+    conf, x0 = _sample_hip(lib, logits, 0.7, 0.0, None, _mode(False, True), noise)
+    assert torch.equal(x0, logits.argmax(-1)) and torch.equal(x0, rx)
+    np.testing.assert_allclose(conf.numpy(), rc.numpy(), atol=1e-6)
+    conf2, x02 = _sample_hip(lib, logits, 0.7, None, None, _mode(False, True), noise)  # None = no filter
+    assert not torch.equal(x02, x0)
+
+
 def test_error_paths(lib):
     H = _hip()
     with pytest.raises(H.DarkHipError):
@@ -356,7 +404,7 @@ def test_philox_exponential_is_torchs_stream(lib, numel):
     assert philox_fill_plan(torch.device(DEV), numel) == (seed, off0, nth) and gen.get_offset() - off0 == adv
 
 
-@pytest.mark.parametrize("T,top_p,top_k,mode", [(0.1, 0.9, 0, 2), (0.5, 0.9, 0, 2), (1.0, 0.0, 0, 0), (0.7, 0.0, 20, 1)])
+@pytest.mark.parametrize("T,top_p,top_k,mode", [(0.1, 0.9, 0, 2), (0.5, 0.9, 0, 2), (1.0, -1.0, 0, 0), (0.7, -1.0, 20, 1)])
 def test_sample_rows_philox_equals_materialised_noise(lib, T, top_p, top_k, mode):
     """The sampler fed by the lazy Philox draws == the sampler fed by torch's exponential_ fill of the same state."""
     H = _hip()

@@ -77,6 +77,11 @@ def _loop_ids(case, goldens):
 
 
 TIE_FREE = {"abd_t01", "abd_t05_s32", "ded_t01", "abd_maskgit", "abd_margin", "abd_origin", "abd_padmask"}
+# Pinned from the MI355X runs (round 2): free runs bit-equal to the reference's goldens, and the only cases allowed to
+# fall back to the teacher-forced near-tie check (flat mini-model distributions at T >= 0.5 / top-k / ragged greedy).
+GOLDEN_EXACT = {"abd_margin", "abd_maskgit", "abd_origin", "abd_padmask", "abd_t01", "ded_t01"}
+ORACLE_EXACT = GOLDEN_EXACT | {"abd_greedy"}   # exact ties at the k-th place: equal to the oracle's device tie order
+NEAR_TIE_CASES = {"abd_t05_s32", "ded_t05_s8", "ded_topk", "rag_t0"}
 NEAR_TIE = 2e-6  # relative: ~16 ulp of fp32; confidences are sums over V terms, so implementations differ by a few ulp
 
 
@@ -115,11 +120,13 @@ def test_loops_match_reference_goldens(mini, goldens, golden_meta):
     goldens bit for bit.  If a free run diverges, the case is replayed under teacher forcing (every step starts
     from the oracle's state) and each disagreeing step must be an fp32 near-tie between the candidates
     (NEAR_TIE).  The mini model (V=512, 2 layers, random weights) gives near-flat, near-identical distributions at
-    neighbouring positions, so ulp-level ties are common there; at least 3 cases must still be bit-exact against
-    the reference goldens, and the real-shape tests below must be exact."""
+    neighbouring positions, so ulp-level ties are common there; WHICH cases are bit-exact against the reference
+    goldens / the oracle and which may take the near-tie route is pinned by name (GOLDEN_EXACT, ORACLE_EXACT,
+    NEAR_TIE_CASES), and the real-shape tests below must be exact."""
     cfg = O.OracleConfig(**{k: v for k, v in golden_meta["mini"].items() if k in O.OracleConfig.__dataclass_fields__})
     w = synth.make_weights(mini.config, seed=0, rich=True)
-    checked = golden_exact = near_tie_cases = 0
+    checked = 0
+    golden_exact, oracle_exact, near_tie = [], [], []
     for case in golden_meta["cases"]["loops"]:
         name, kw = case["name"], dict(case["kw"])
         if name == "ded_algtemp":
@@ -142,12 +149,13 @@ def test_loops_match_reference_goldens(mini, goldens, golden_meta):
         oh = torch.stack(_oracle_loop(w, cfg, ids_cpu, am_cpu, kw, case["seed"], otr))
         checked += 1
         if torch.equal(hist, oh):
+            oracle_exact.append(name)
             if name in TIE_FREE:
                 assert np.array_equal(hist.numpy(), goldens[name + "_hist"]), f"{name} vs reference golden"
-                golden_exact += 1
+                golden_exact.append(name)
             continue
         assert kw["alg"] != "origin", name
-        near_tie_cases += 1
+        near_tie.append(name)
         print(f"{name}: free run diverges from the oracle; checking every step under teacher forcing")
         forced = []
         run(_state_hook=lambda i, x: (forced.append(x.cpu().clone()), oh[i])[1])
@@ -156,8 +164,13 @@ def test_loops_match_reference_goldens(mini, goldens, golden_meta):
             if not torch.equal(hx, oh[i]):
                 prev = oh[i - 1] if i else x_init
                 assert _explained_by_near_tie(prev, hx, oh[i], otr.confidence[i], otr.k[i]), f"{name} step {i}"
-    print(f"loops: {checked} cases, {golden_exact} bit-exact vs reference goldens, {near_tie_cases} with fp32 near-ties")
-    assert checked >= 11 and near_tie_cases <= 5 and golden_exact >= 3, (checked, near_tie_cases, golden_exact)
+    print(f"loops: {checked} cases; bit-exact vs reference goldens {sorted(golden_exact)}; bit-exact vs the oracle "
+          f"{sorted(oracle_exact)}; fp32 near-ties {sorted(near_tie)}")
+    # Pinned: a case that stops being bit-exact is a regression even if its steps are still near-ties.
+    assert checked == 11
+    assert set(golden_exact) >= GOLDEN_EXACT, sorted(GOLDEN_EXACT - set(golden_exact))
+    assert set(oracle_exact) >= ORACLE_EXACT, sorted(ORACLE_EXACT - set(oracle_exact))
+    assert set(near_tie) <= NEAR_TIE_CASES, sorted(set(near_tie) - NEAR_TIE_CASES)
 
 
 def test_alg_temp_property(mini, goldens):

@@ -146,3 +146,23 @@ def test_think_sample_loops(mini):
                                 temperature=kw["temperature"], top_p=kw["top_p"], think_sample=True,
                                 think_sample_interval=kw["think_sample_interval"], sep_token_id=synth.SEP)
         assert np.array_equal(torch.stack(hist).numpy(), g[c["name"] + "_hist"]), c["name"]
+
+
+# ---- real-width fixtures of tests/golden/make_goldens_real.py (deduction batch, config 3's vocabulary)
+def test_real_width_goldens_round2():
+    """The oracle against the reference's histories for config 3's vocabulary (V = 25427, 2-layer cut, abduction
+    T = 0.1 and deduction T = 0.5) and for a 10-layer deduction batch (33 masks, 32 steps, T = 0.1).  The T = 0.5
+    deduction and the 64-row config-1 fixtures of the same file are checked on the GPU only (CPU suite time)."""
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "reference_goldens_real.json")) as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(here, "reference_goldens_real.npz"))
+    assert synth.vocab_size(**meta["dbpedia"]) == meta["cfg3"]["vocab_size"] == 25427
+    by_name = {c["name"]: c for c in meta["cases"]}
+    for name, cfg_kw in (("cfg3_abd_t01", meta["cfg3"]), ("cfg3_ded_t05", meta["cfg3"]), ("real_ded_t01", meta["real"])):
+        cfg = _cfg(cfg_kw)
+        w = synth.make_weights(cfg, seed=0, rich=False)
+        ids = torch.from_numpy(g[name + "_ids"])
+        assert np.array_equal(_run_loop(cfg, w, ids, by_name[name]), g[name + "_hist"]), name
