@@ -47,6 +47,10 @@ SIGNATURES = {
                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "dark_lm_head_rows": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_int64, C.c_void_p]),
+    "dark_noalloc_init": (C.c_int, []),
+    "dark_noalloc_max_rows": (C.c_size_t, [C.POINTER(ModelDesc)]),
+    "dark_lm_head_rows_noalloc": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_int64, C.c_void_p]),
     "dark_mask_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
     "dark_sample_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,

@@ -96,6 +96,31 @@ static int lm_head_rows(const dark_model_desc* m, const float* hidden, const int
   return DARK_OK;
 }
 
+// ---- scratch of the allocation-free entry point (dark_lm_head_rows_noalloc): the gathered, normalised rows that
+// dark_lm_head_rows keeps in its caller-provided workspace live here instead.  Every GPU the library runs on holds
+// its own copy of the array until the process ends; the name below is only a host-side handle, the device address is
+// resolved per device with hipGetSymbolAddress and that pointer is what the kernels receive.
+constexpr size_t kNoAllocScratchBytes = DARK_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+static void* g_scratch_ptr[DARK_MAX_DEVICES] = {};
+static std::atomic<int> g_scratch_ready[DARK_MAX_DEVICES] = {};
+
+// Device address of `scratch` on the CURRENT device (resolved once per device, with that device current).
+static int scratch_on_current_device(void** out) {
+  int dev = 0;
+  DARK_CHECK_HIP(hipGetDevice(&dev));
+  DARK_CHECK_ARG(dev >= 0 && dev < DARK_MAX_DEVICES, "device ordinal %d out of range", dev);
+  if (!g_scratch_ready[dev].load(std::memory_order_acquire)) {
+    void* p = nullptr;
+    DARK_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    DARK_CHECK_ARG(p != nullptr, "hipGetSymbolAddress returned a null scratch address on device %d", dev);
+    g_scratch_ptr[dev] = p;  // racing threads resolve the same address: benign
+    g_scratch_ready[dev].store(1, std::memory_order_release);
+  }
+  *out = g_scratch_ptr[dev];
+  return DARK_OK;
+}
+
 struct StepWs {
   char* fwd;
   float* hidden;
@@ -170,6 +195,32 @@ int dark_lm_head_rows(const dark_model_desc* m, const float* hidden, const int32
                       size_t workspace_bytes, float* logits, int64_t ldl, void* stream) {
   // src_rows entries are clamped to < 2^30 rows; callers pass indices produced by dark_mask_rows
   return lm_head_rows(m, hidden, src_rows, 1 << 30, M, workspace, workspace_bytes, logits, ldl, (hipStream_t)stream);
+}
+
+int dark_noalloc_init(void) {
+  void* p = nullptr;
+  return scratch_on_current_device(&p);
+}
+
+size_t dark_noalloc_max_rows(const dark_model_desc* m) {
+  if (!m || m->d <= 0) return 0;
+  return kNoAllocScratchBytes / ((size_t)m->d * esize(m->dtype));
+}
+
+int dark_lm_head_rows_noalloc(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M,
+                              float* logits, int64_t ldl, void* stream) {
+  DARK_TRY(check_model(m));
+  if (M <= 0) return DARK_OK;
+  const size_t need = align_up((size_t)M * m->d * esize(m->dtype), 256);
+  DARK_CHECK_ARG(need <= kNoAllocScratchBytes,
+                 "lm_head_rows_noalloc: M=%d rows of %d %s values need %zu bytes of scratch, the static buffer holds "
+                 "%zu (at most %zu rows); use dark_lm_head_rows with a workspace for larger batches",
+                 M, m->d, m->dtype == DARK_BF16 ? "bf16" : "fp32", need, kNoAllocScratchBytes,
+                 kNoAllocScratchBytes / ((size_t)m->d * esize(m->dtype)));
+  void* ws = nullptr;
+  DARK_TRY(scratch_on_current_device(&ws));
+  // from here on only `ws` (the resolved device pointer) is used, never the array's name
+  return lm_head_rows(m, hidden, src_rows, 1 << 30, M, ws, kNoAllocScratchBytes, logits, ldl, (hipStream_t)stream);
 }
 
 int dark_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* row_index, int32_t* src_rows,

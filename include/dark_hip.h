@@ -102,6 +102,23 @@ int dark_forward_hidden(const dark_model_desc* m, const int64_t* ids, const int3
 int dark_lm_head_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M,
                       void* workspace, size_t workspace_bytes, float* logits, int64_t ldl, void* stream);
 
+/* Allocation-free variant of dark_lm_head_rows.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate or pass a workspace -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * The gathered + normalised rows that dark_lm_head_rows keeps in `workspace` live in a static device array of
+ * DARK_NOALLOC_SCRATCH_BYTES inside the library (one copy per GPU, held until the process ends), so
+ * M * d * sizeof(model dtype) must not exceed it (dark_noalloc_max_rows(m) rows: 5461 bf16 / 2730 fp32 rows at
+ * d = 768); larger M is refused with DARK_ERR_ARG.  The call makes no hipMalloc / hipFree and no allocating library
+ * call.  Every call on a GPU shares that GPU's array: the array is fully rewritten for the M rows of each call, so
+ * nothing has to be cleared, but two calls that OVERLAP on one GPU (different streams or host threads) race on it.
+ * dark_noalloc_init() resolves the array's device address for the CURRENT device (hipGetSymbolAddress); the entry
+ * point does the same on its first call on a device, so init is only needed to keep that lookup out of a capture.
+ * Results are bit-identical to dark_lm_head_rows. */
+#define DARK_NOALLOC_SCRATCH_BYTES (8u << 20)
+int dark_noalloc_init(void);
+size_t dark_noalloc_max_rows(const dark_model_desc* m);
+int dark_lm_head_rows_noalloc(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M,
+                              float* logits, int64_t ldl, void* stream);
+
 /* `mask_index = (x == mask_token_id)` + the row-major compaction `logits[mask_index]` uses
  * (generation_utils.py:489, :501).  row_index[m] = b*N+j of the m-th masked position,
  * src_rows[m] = b*N + max(j-1, 0) (the logit shift, :496); *count = M.  Buffers hold B*N ints. */
