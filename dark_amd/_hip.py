@@ -45,6 +45,10 @@ SIGNATURES = {
                                               C.POINTER(C.c_size_t)]),
     "dark_forward_hidden": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "dark_forward_hidden_begin": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "dark_forward_hidden_rows": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dark_lm_head_rows": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_int64, C.c_void_p]),
     "dark_noalloc_init": (C.c_int, []),

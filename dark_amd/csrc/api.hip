@@ -50,9 +50,11 @@ static FwdWs carve_fwd(const dark_model_desc* m, size_t rows, char* base) {
   return w;
 }
 
+// `tail_rows` = false: the whole body.  true: stop after the LAST layer's attention -- what is left of that layer
+// (o_proj, residual, norm, MLP, residual) only matters for the rows the head will read and is done by forward_tail.
 static int forward_hidden(const dark_model_desc* m, const int64_t* ids, const int32_t* pos,
                           const uint8_t* key_mask, int B, int N, void* workspace, size_t ws_bytes,
-                          float* hidden, hipStream_t st) {
+                          float* hidden, hipStream_t st, bool tail_rows = false) {
   DARK_TRY(check_model(m));
   DARK_CHECK_ARG(B > 0 && N > 0 && N <= 128, "forward: B=%d N=%d (N must be in [1,128])", B, N);
   DARK_CHECK_ARG((int64_t)B * N < (1ll << 30), "forward: B*N too large");
@@ -75,11 +77,36 @@ static int forward_hidden(const dark_model_desc* m, const int64_t* ids, const in
     DARK_TRY(launch_gemm(m->dtype, EPI_BIAS, w.xn, L.w_qkv, L.b_qkv, w.qkv, M, 3 * d, d, 3 * d, st));
     DARK_TRY(launch_attention(m->dtype, w.qkv, m->rope_cos, m->rope_sin, pos, key_mask, w.att, B, N, m->n_heads,
                               m->head_dim, m->max_pos, st));
+    if (tail_rows && l == m->n_layers - 1) break;
     DARK_TRY(launch_gemm(m->dtype, EPI_RESID, w.att, L.w_o, nullptr, hidden, M, d, d, d, st));
     DARK_TRY(launch_rmsnorm(m->dtype, hidden, L.ln2, w.xn, nullptr, M, M, d, m->rms_eps, st));
     DARK_TRY(launch_gemm(m->dtype, EPI_SWIGLU, w.xn, L.w_gu, nullptr, w.act, M, 2 * m->ff, d, m->ff, st));
     DARK_TRY(launch_gemm(m->dtype, EPI_RESID, w.act, L.w_down, nullptr, hidden, M, d, m->ff, d, st));
   }
+  return DARK_OK;
+}
+
+// The rest of the last layer for the R rows in `rows` only (bidirectional attention needs every position's K/V in
+// every layer, but nothing reads the last layer's output except the LM head, which reads R << B*N rows):
+// hidden_rows[r] = what the full body leaves in hidden[rows[r]], bit for bit -- every GEMM output element is the same
+// K-ordered dot product whichever rows share its tile.  The compact operands reuse the (now dead) xn / qkv / act regions.
+static int forward_tail(const dark_model_desc* m, int B, int N, const int32_t* rows, int R, void* workspace,
+                        size_t ws_bytes, const float* hidden, float* hidden_rows, hipStream_t st) {
+  DARK_TRY(check_model(m));
+  DARK_CHECK_ARG(B > 0 && N > 0 && R >= 0 && R <= B * N, "forward_tail: bad B=%d N=%d rows=%d", B, N, R);
+  if (R == 0) return DARK_OK;
+  DARK_CHECK_ARG(rows && workspace && hidden && hidden_rows, "forward_tail: null pointer");
+  const int d = m->d, n_src = B * N;
+  FwdWs w = carve_fwd(m, (size_t)n_src, (char*)workspace);
+  DARK_CHECK_ARG(ws_bytes >= w.total, "forward_tail: workspace %zu < required %zu bytes", ws_bytes, w.total);
+  if (m->n_layers == 0) return launch_gather_rows(m->dtype, nullptr, nullptr, hidden, hidden_rows, rows, n_src, R, d, st);
+  const dark_layer_weights& L = m->layers[m->n_layers - 1];
+  char *att_c = w.xn, *xn_c = w.qkv;
+  DARK_TRY(launch_gather_rows(m->dtype, w.att, att_c, hidden, hidden_rows, rows, n_src, R, d, st));
+  DARK_TRY(launch_gemm(m->dtype, EPI_RESID, att_c, L.w_o, nullptr, hidden_rows, R, d, d, d, st));
+  DARK_TRY(launch_rmsnorm(m->dtype, hidden_rows, L.ln2, xn_c, nullptr, R, R, d, m->rms_eps, st));
+  DARK_TRY(launch_gemm(m->dtype, EPI_SWIGLU, xn_c, L.w_gu, nullptr, w.act, R, 2 * m->ff, d, m->ff, st));
+  DARK_TRY(launch_gemm(m->dtype, EPI_RESID, w.act, L.w_down, nullptr, hidden_rows, R, d, m->ff, d, st));
   return DARK_OK;
 }
 
@@ -129,6 +156,7 @@ struct StepWs {
   float* logits;
   float* conf;
   int64_t* x0;
+  float* hidden_rows;
   size_t fwd_bytes, head_bytes, total;
 };
 static StepWs carve_step(const dark_model_desc* m, int B, int N, int M, char* base) {
@@ -147,6 +175,7 @@ static StepWs carve_step(const dark_model_desc* m, int B, int N, int M, char* ba
   w.logits = (float*)take((size_t)M * m->vocab * 4);
   w.conf = (float*)take((size_t)M * 4);
   w.x0 = (int64_t*)take((size_t)M * 8);
+  w.hidden_rows = (float*)take((size_t)M * m->d * 4);
   w.total = off;
   return w;
 }
@@ -189,6 +218,17 @@ int dark_step_workspace_offsets(const dark_model_desc* m, int B, int N, int M, s
 int dark_forward_hidden(const dark_model_desc* m, const int64_t* ids, const int32_t* pos, const uint8_t* key_mask,
                         int B, int N, void* workspace, size_t workspace_bytes, float* hidden, void* stream) {
   return forward_hidden(m, ids, pos, key_mask, B, N, workspace, workspace_bytes, hidden, (hipStream_t)stream);
+}
+
+int dark_forward_hidden_begin(const dark_model_desc* m, const int64_t* ids, const int32_t* pos,
+                              const uint8_t* key_mask, int B, int N, void* workspace, size_t workspace_bytes,
+                              float* hidden, void* stream) {
+  return forward_hidden(m, ids, pos, key_mask, B, N, workspace, workspace_bytes, hidden, (hipStream_t)stream, true);
+}
+
+int dark_forward_hidden_rows(const dark_model_desc* m, int B, int N, const int32_t* rows, int n_rows, void* workspace,
+                             size_t workspace_bytes, const float* hidden, float* hidden_rows, void* stream) {
+  return forward_tail(m, B, N, rows, n_rows, workspace, workspace_bytes, hidden, hidden_rows, (hipStream_t)stream);
 }
 
 int dark_lm_head_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M, void* workspace,
@@ -265,10 +305,12 @@ int dark_denoise_step(const dark_model_desc* m, int64_t* x, const int32_t* pos, 
   StepWs w = carve_step(m, B, N, M, (char*)workspace);
   DARK_CHECK_ARG(workspace_bytes >= w.total, "denoise_step: workspace %zu < required %zu bytes", workspace_bytes,
                  w.total);
-  DARK_TRY(forward_hidden(m, x, pos, key_mask, B, N, w.fwd, w.fwd_bytes, w.hidden, st));
-  if (M == 0) return DARK_OK;
+  if (M == 0) return forward_hidden(m, x, pos, key_mask, B, N, w.fwd, w.fwd_bytes, w.hidden, st);
+  // the last layer's o_proj / MLP only for the M rows the head reads (dark_forward_hidden_begin / _rows)
+  DARK_TRY(forward_hidden(m, x, pos, key_mask, B, N, w.fwd, w.fwd_bytes, w.hidden, st, true));
   DARK_TRY(launch_mask_rows(x, B, N, mask_id, w.row_index, w.src_rows, w.count, st));
-  DARK_TRY(lm_head_rows(m, w.hidden, w.src_rows, B * N, M, w.head, w.head_bytes, w.logits, m->vocab, st));
+  DARK_TRY(forward_tail(m, B, N, w.src_rows, M, w.fwd, w.fwd_bytes, w.hidden, w.hidden_rows, st));
+  DARK_TRY(lm_head_rows(m, w.hidden_rows, nullptr, M, M, w.head, w.head_bytes, w.logits, m->vocab, st));
   DARK_TRY(launch_sample(w.logits, m->vocab, M, m->vocab, temperature, top_p, top_k, conf_mode, noise, m->vocab,
                          w.conf, w.x0, st));
   DARK_TRY(launch_commit(x, B, N, mask_id, w.row_index, M, w.conf, w.x0, k, st));

@@ -154,6 +154,10 @@ int launch_embed_norm(int dtype, const int64_t* ids, const void* table, float* o
                       const float* ln_w, float eps, void* xn, hipStream_t st);
 int launch_rmsnorm(int dtype, const float* x, const float* w, void* out, const int32_t* src_rows, int n_src,
                    int M, int d, float eps, hipStream_t st);
+// att_out[r] = att[rows[r]] (model dtype; both nullable together) and x_out[r] = x[rows[r]] (fp32), rows clamped to
+// [0, n_src)
+int launch_gather_rows(int dtype, const void* att, void* att_out, const float* x, float* x_out, const int32_t* rows,
+                       int n_src, int R, int d, hipStream_t st);
 int launch_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                      const uint8_t* kmask, void* out, int B, int N, int H, int HD, int max_pos,
                      hipStream_t st);

@@ -177,6 +177,40 @@ int launch_rmsnorm(int dtype, const float* x, const float* w, void* out, const i
   return DARK_OK;
 }
 
+// ------------------------------------------------------------------ row gather for the last layer's tail
+// One wave per output row: the attention output row (model dtype) and the residual row (fp32) of position rows[r].
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ att, T* __restrict__ att_out,
+                                                          const float* __restrict__ x, float* __restrict__ x_out,
+                                                          const int32_t* __restrict__ rows, int n_src, int R, int d) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  int64_t src = rows[r];
+  src = src < 0 ? 0 : (src >= n_src ? n_src - 1 : src);
+  for (int c = lane * 4; c < d; c += 256) *(float4*)(x_out + (int64_t)r * d + c) = *(const float4*)(x + src * d + c);
+  if (att) {
+    constexpr int E = 16 / (int)sizeof(T);  // elements per 16-byte piece
+    for (int c = lane * E; c < d; c += 64 * E)
+      *(uint4*)(att_out + (int64_t)r * d + c) = *(const uint4*)(att + src * d + c);
+  }
+}
+
+int launch_gather_rows(int dtype, const void* att, void* att_out, const float* x, float* x_out, const int32_t* rows,
+                       int n_src, int R, int d, hipStream_t st) {
+  DARK_CHECK_ARG(d % 8 == 0, "gather_rows: d=%d must be a multiple of 8", d);
+  DARK_CHECK_ARG(x && x_out && rows && (att == nullptr) == (att_out == nullptr), "gather_rows: null pointer");
+  if (R <= 0) return DARK_OK;
+  const dim3 grid(cdiv(R, 4)), block(256);
+  if (dtype == DARK_BF16)
+    hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)att, (bf16_t*)att_out, x, x_out, rows,
+                       n_src, R, d);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<float>, grid, block, 0, st, (const float*)att, (float*)att_out, x, x_out, rows,
+                       n_src, R, d);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
 // ------------------------------------------------------------------ mask rows (generation_utils.py:489, :496, :501)
 // Single workgroup stream compaction over the flattened [B*N] ids: row-major order is the order
 // `logits[mask_index]` enumerates masked positions in.

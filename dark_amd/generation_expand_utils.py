@@ -299,8 +299,8 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
                                                    _hip.ptr(st.src_rows), _hip.ptr(buf.active), _hip.ptr(st.count),
                                                    s))
             st.hidden_valid = False
-            st.forward_hidden(x, buf.pos, buf.key_mask)
-            logits = st.head_rows(st.src_rows, M)
+            st.forward_begin(x, buf.pos, buf.key_mask)   # the last layer's o_proj / MLP only for the M masked rows
+            logits = st.head_rows(None, M, st.forward_rows(M))
             _hip.check(lib.dark_expand_block_logit(_hip.ptr(logits), V, V, _hip.ptr(st.row_index), M, B, N,
                                                    _hip.ptr(win), _hip.ptr(budget), int(expand_id), s))
             noise = philox = None

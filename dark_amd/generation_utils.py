@@ -371,7 +371,9 @@ class DreamGenerationMixin:
         skip = ctx.skip_noop and trace is None
         if not (skip and st.hidden_valid):
             st.mask_rows(x, mask_id)              # row_index / src_rows / count, then async count read-back
-            st.forward_hidden(x, pos, key_mask)   # enqueued before the host waits for the count
+            # enqueued before the host waits for the count: everything up to the last layer's attention; the rest of
+            # that layer is only needed for the M rows the head reads and follows once M is known (forward_rows)
+            st.forward_begin(x, pos, key_mask)
             st.hidden_valid = True                # ... for as long as x does not change
         M = st.wait_count()
         Mg, Bg = (M, B) if ctx.count_reduce is None else ctx.count_reduce(st.count[:1], B)
@@ -389,6 +391,8 @@ class DreamGenerationMixin:
                 noise = self._draw_noise(step, M, V, x.device, noise_fn)
         if skip and k == 0:
             return  # nothing is committed: the draw above was this step's only effect
+        if not st.rows_valid:
+            st.forward_rows(M)
         conf, x0 = st.head_and_sample(M, temperature, top_p, top_k, conf_mode, noise, philox)
         if trace is not None:
             trace.setdefault("confidence", []).append(conf.clone())

@@ -143,7 +143,9 @@ class HipState:
         self.logits = None
         self.conf = torch.empty(rows, dtype=torch.float32, device=dev)
         self.x0 = torch.empty(rows, dtype=torch.int64, device=dev)
+        self.hidden_rows = torch.empty((rows, cfg.hidden_size), dtype=torch.float32, device=dev)
         self.hidden_valid = False  # hidden / row_index / count describe the caller's current x
+        self.rows_valid = False    # hidden_rows holds the last layer's output for src_rows[:M] of that x
 
     def _s(self) -> int:
         return _hip.stream_ptr(self.pk.device)
@@ -156,10 +158,26 @@ class HipState:
             self.logits = torch.empty(M * self.cfg.vocab_size, dtype=torch.float32, device=self.pk.device)
 
     def forward_hidden(self, x, pos, key_mask) -> torch.Tensor:
+        self.rows_valid = False
         _hip.check(self.lib.dark_forward_hidden(self.pk.ref, _hip.ptr(x), _hip.ptr(pos), _hip.ptr(key_mask),
                                                 self.B, self.N, _hip.ptr(self.fwd_ws), self.fwd_bytes,
                                                 _hip.ptr(self.hidden), self._s()))
         return self.hidden
+
+    def forward_begin(self, x, pos, key_mask) -> None:
+        """Everything of the body that does not depend on which rows the head will read (dark_forward_hidden_begin)."""
+        _hip.check(self.lib.dark_forward_hidden_begin(self.pk.ref, _hip.ptr(x), _hip.ptr(pos), _hip.ptr(key_mask),
+                                                      self.B, self.N, _hip.ptr(self.fwd_ws), self.fwd_bytes,
+                                                      _hip.ptr(self.hidden), self._s()))
+        self.rows_valid = False
+
+    def forward_rows(self, M: int) -> torch.Tensor:
+        """The rest of the last layer for src_rows[:M] only -> hidden_rows[:M] (dark_forward_hidden_rows)."""
+        _hip.check(self.lib.dark_forward_hidden_rows(self.pk.ref, self.B, self.N, _hip.ptr(self.src_rows), M,
+                                                     _hip.ptr(self.fwd_ws), self.fwd_bytes, _hip.ptr(self.hidden),
+                                                     _hip.ptr(self.hidden_rows), self._s()))
+        self.rows_valid = True
+        return self.hidden_rows
 
     def mask_rows(self, x, mask_id) -> None:
         _hip.check(self.lib.dark_mask_rows(_hip.ptr(x), self.B, self.N, int(mask_id), _hip.ptr(self.row_index),
@@ -171,10 +189,12 @@ class HipState:
         self.count_event.synchronize()
         return int(self.count_host[0])
 
-    def head_rows(self, src_rows: Optional[torch.Tensor], M: int) -> torch.Tensor:
+    def head_rows(self, src_rows: Optional[torch.Tensor], M: int, hidden: Optional[torch.Tensor] = None
+                  ) -> torch.Tensor:
         V = self.cfg.vocab_size
         self._ensure_head(M)
-        _hip.check(self.lib.dark_lm_head_rows(self.pk.ref, _hip.ptr(self.hidden), _hip.ptr(src_rows), M,
+        hidden = self.hidden if hidden is None else hidden
+        _hip.check(self.lib.dark_lm_head_rows(self.pk.ref, _hip.ptr(hidden), _hip.ptr(src_rows), M,
                                               _hip.ptr(self.head_ws), self.head_ws.numel(), _hip.ptr(self.logits),
                                               V, self._s()))
         return self.logits[:M * V].view(M, V)
@@ -193,9 +213,10 @@ class HipState:
         return conf, x0
 
     def head_and_sample(self, M, temperature, top_p, top_k, conf_mode, noise, philox=None):
-        """`philox` = (seed, offset, nthreads) from generation_utils.philox_fill_plan: draws computed in the kernel."""
+        """`philox` = (seed, offset, nthreads) from generation_utils.philox_fill_plan: draws computed in the kernel.
+        Reads hidden_rows[:M] (forward_begin + forward_rows) when it is current, else hidden[src_rows[:M]]."""
         V = self.cfg.vocab_size
-        logits = self.head_rows(self.src_rows, M)
+        logits = self.head_rows(None, M, self.hidden_rows) if self.rows_valid else self.head_rows(self.src_rows, M)
         conf, x0 = self.conf[:M], self.x0[:M]
         if philox is not None:
             _hip.check(self.lib.dark_sample_rows_philox(_hip.ptr(logits), V, M, V, float(temperature), float(top_p),

@@ -94,6 +94,22 @@ int dark_forward_hidden(const dark_model_desc* m, const int64_t* ids, const int3
                         const uint8_t* key_mask, int B, int N, void* workspace, size_t workspace_bytes,
                         float* hidden, void* stream);
 
+/* The same body in two calls, for loops that only need the rows the sampler reads.  Bidirectional attention needs
+ * every position's keys and values in every layer, but the OUTPUT of the last layer is read by nothing except the LM
+ * head, and the head reads only `src_rows` (the reference evaluates all B*N rows, modeling_dream_length.py:688-721,
+ * and drops the others at generation_utils.py:501).
+ *   dark_forward_hidden_begin: everything up to and including the last layer's attention (independent of the rows);
+ *     `hidden` then holds the residual stream BEFORE the last layer's o_proj.
+ *   dark_forward_hidden_rows: o_proj + residual + RMSNorm + SwiGLU MLP + residual of the last layer for `rows`
+ *     [n_rows] int32 only: hidden_rows [n_rows, d] fp32 OUT = the rows hidden[rows[r]] that dark_forward_hidden
+ *     would have produced, bit for bit.  Same workspace as the begin call (its contents are consumed).
+ * Feed hidden_rows to dark_lm_head_rows with src_rows = NULL. */
+int dark_forward_hidden_begin(const dark_model_desc* m, const int64_t* ids, const int32_t* pos,
+                              const uint8_t* key_mask, int B, int N, void* workspace, size_t workspace_bytes,
+                              float* hidden, void* stream);
+int dark_forward_hidden_rows(const dark_model_desc* m, int B, int N, const int32_t* rows, int n_rows, void* workspace,
+                             size_t workspace_bytes, const float* hidden, float* hidden_rows, void* stream);
+
 /* Final RMSNorm + LM head on selected rows.  Replaces `self.norm` (:721) and `lm_head` (:809)
  * restricted to the rows the sampler consumes, including the logit shift of
  * generation_utils.py:496 when `src_rows` comes from dark_mask_rows.
@@ -163,7 +179,8 @@ int dark_commit_topk(int64_t* x, int B, int N, int64_t mask_id, const int32_t* r
  *   noise [M, V] fp32 or NULL when temperature == 0;  k = number_transfer_tokens of this step
  *   workspace: dark_step_workspace_bytes(m, B, N, M) bytes */
 size_t dark_step_workspace_bytes(const dark_model_desc* m, int B, int N, int M);
-/* Byte offsets inside the step workspace of {hidden fp32 [B*N,d], row_index i32, src_rows i32, count i32,
+/* Byte offsets inside the step workspace of {hidden fp32 [B*N,d] (the residual stream before the last layer's o_proj
+ * when M > 0: the step evaluates the rest of that layer for the M masked rows only), row_index i32, src_rows i32, count i32,
  * logits fp32 [M,V], conf fp32 [M], x0 i64 [M]} so callers (hooks, parity tests) can read the
  * intermediates that generation_utils.py:495-517 exposes as Python tensors. */
 int dark_step_workspace_offsets(const dark_model_desc* m, int B, int N, int M, size_t* out7);

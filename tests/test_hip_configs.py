@@ -255,6 +255,41 @@ def test_denoise_step_entry_point(real):
                                          _hip.ptr(ws), 1024, stream))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_forward_rows_equals_full_forward(real, dtype):
+    """dark_forward_hidden_begin + dark_forward_hidden_rows (the last layer's o_proj / MLP for the rows the head reads
+    only) against dark_forward_hidden: the selected rows of the residual stream bit for bit, padded attention mask and
+    duplicate / unsorted row indices included; 0 and 1 layers as edge cases."""
+    meta, _ = real
+    lib = _hip.load()
+    for L in (3, 1, 0):
+        m = _model(dict(meta["real"], num_hidden_layers=L), dtype)
+        pk = m.packed()
+        B, N, d = 24, 46, 768
+        x = torch.nn.functional.pad(synth.make_inputs(B, "ded", seed=6), (0, 1), value=synth.MASK).to(DEV).contiguous()
+        km = torch.ones(B, N, dtype=torch.uint8, device=DEV)
+        km[1, 30:40] = 0
+        pos = (km.long().cumsum(-1) - 1).masked_fill(km == 0, 1).to(torch.int32).contiguous()
+        g = torch.Generator().manual_seed(L)
+        rows = torch.randint(0, B * N, (389,), generator=g).to(torch.int32)
+        rows[5] = rows[9]
+        rows_d = rows.to(DEV)
+        nb = lib.dark_forward_workspace_bytes(pk.ref, B, N)
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        stream = torch.cuda.current_stream().cuda_stream
+        full = torch.empty(B * N, d, device=DEV)
+        _hip.check(lib.dark_forward_hidden(pk.ref, _hip.ptr(x), _hip.ptr(pos), _hip.ptr(km), B, N, _hip.ptr(ws), nb,
+                                           _hip.ptr(full), stream))
+        part = torch.full((B * N, d), float("nan"), device=DEV)
+        out = torch.full((rows.numel(), d), float("nan"), device=DEV)
+        _hip.check(lib.dark_forward_hidden_begin(pk.ref, _hip.ptr(x), _hip.ptr(pos), _hip.ptr(km), B, N, _hip.ptr(ws),
+                                                 nb, _hip.ptr(part), stream))
+        _hip.check(lib.dark_forward_hidden_rows(pk.ref, B, N, _hip.ptr(rows_d), rows.numel(), _hip.ptr(ws), nb,
+                                                _hip.ptr(part), _hip.ptr(out), stream))
+        torch.cuda.synchronize()
+        assert torch.equal(out, full[rows_d.long()]), (L, dtype)
+
+
 # --------------------------------------------------------------------------- boundary behaviour
 def test_int32_ids_are_accepted(real):
     """nn.Embedding in the reference takes int32 ids too (modeling_dream_length.py:665): the boundary casts once."""
