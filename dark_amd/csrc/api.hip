@@ -323,6 +323,12 @@ int dark_prof_read(double* total_ms, double* total_flops, int* launches) {
   return prof_read(total_ms, total_flops, launches);
 }
 
+int dark_dbg_set_gemm_variant(int variant) {
+  DARK_CHECK_ARG(variant >= 0 && variant <= 2, "set_gemm_variant: %d", variant);
+  set_gemm_variant(variant);
+  return DARK_OK;
+}
+
 // ---- unit-test hooks: single-kernel launches (tests/test_hip_kernels.py) ----
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                   int64_t ldo, void* stream) {

@@ -144,6 +144,12 @@ enum Epi { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_F32 = 3, EPI_LSE = 4
 int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out,
                 int M, int N, int K, int64_t ldo, hipStream_t st);
 
+// gemm256.hip: persistent 256 x 256 bf16 kernel (EPI_BIAS / EPI_SWIGLU / EPI_F32); w_rows = allocated rows of W
+bool p256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias);
+int launch_gemm_p256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                     int64_t ldo, int w_rows, hipStream_t st);
+void set_gemm_variant(int v);
+
 int prof_select(int epi);
 int prof_read(double* total_ms, double* total_flops, int* launches);
 

@@ -574,6 +574,23 @@ int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* b
   return rc;
 }
 
+// 0 = automatic choice, 1 = always the 128-row kernels of this file, 2 = the persistent 256 x 256 kernel (gemm256.hip)
+// wherever it supports the shape.  Test / measurement hook (dark_dbg_set_gemm_variant).
+static std::atomic<int> g_gemm_variant{0};
+void set_gemm_variant(int v) { g_gemm_variant.store(v, std::memory_order_relaxed); }
+
+static bool use_p256(int dtype, int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias) {
+  if (dtype != DARK_BF16) return false;
+  const int v = g_gemm_variant.load(std::memory_order_relaxed);
+  if (v == 1 || !p256_supports(epi, M, N, K, ldo, out, bias)) return false;
+  if (v == 2) return true;
+  // Automatic choice, from the A/B in tools/gemm_ab.py (one process, interleaved rounds, M = 23552): the LM head
+  // (fp32 out, N = 15080) runs 13 % faster on the 256-wide persistent kernel (606 vs 698 us); gate/up ties (202.5 vs
+  // 203.4 us: its SwiGLU epilogue is exposed at one workgroup per CU) and q/k/v loses to tile quantisation (828
+  // tiles over 256 CUs).  Small row counts leave the 256 CUs short of tiles.
+  return epi == EPI_F32 && (int64_t)cdiv(M, 256) * cdiv(N, 256) >= 512;
+}
+
 static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                             int N, int K, int64_t ldo, hipStream_t st) {
   DARK_CHECK_ARG(dtype == DARK_F32 || dtype == DARK_BF16, "gemm: bad dtype %d", dtype);
@@ -581,6 +598,10 @@ static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, co
   DARK_CHECK_ARG(K % 64 == 0, "gemm: K=%d must be a multiple of 64", K);
   DARK_CHECK_ARG(M < (1 << 24) && N < (1 << 24), "gemm: M=%d N=%d too large", M, N);
   DARK_CHECK_ARG(A && W && out, "gemm: null operand");
+  if (use_p256(dtype, epi, M, N, K, ldo, out, bias)) {
+    DARK_CHECK_ARG(epi != EPI_BIAS || bias != nullptr, "gemm: EPI_BIAS needs a bias");
+    return launch_gemm_p256(epi, A, W, bias, out, M, N, K, ldo, cdiv(N, 128) * 128, st);
+  }
   switch (epi) {
     case EPI_BIAS:
       DARK_CHECK_ARG(bias != nullptr, "gemm: EPI_BIAS needs a bias");

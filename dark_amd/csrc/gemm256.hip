@@ -1,0 +1,287 @@
+// Persistent 256 x 256 bf16 GEMM for the wide projections of the denoise forward (gate/up with the fused SwiGLU,
+// q/k/v with bias): C[M,N] = A[M,K] * W[N,K]^T, both operands K-contiguous.
+//
+// Replaces the same nn.Linear calls as gemm.hip (modeling_dream_length.py:221-222, :381-383) for the shapes where a
+// 256-wide macro tile quantises well; gemm.hip keeps the N = 768 residual GEMMs and the LM head.
+//
+// Why another kernel: the 128 x 192 kernel of gemm.hip moves (128 + 192) * 128 B from L2 into LDS per 128*192*64
+// MACs and reads 10 fragments per 24 MFMAs; a 256 x 256 tile with 128 x 64 per wave moves 39 % fewer bytes per MAC
+// through the LDS-DMA path and reads 12 fragments per 32 MFMAs.  At 128 KiB of LDS only ONE workgroup fits a CU, so
+// what the second workgroup did for gemm.hip (covering the other's barrier, DMA wait, prologue and epilogue) has to
+// come from the structure of the single workgroup:
+//   * 8 waves (2 x 4), two per SIMD; fragments are double-buffered in registers per half K-tile: the ds_read_b128 of
+//     half h+1 are issued in front of the 32 MFMAs of half h, so LDS latency never sits in front of an MFMA;
+//   * ONE barrier per K-tile, in the middle of the tile, in front of which every wave waits for its own LDS-DMA of
+//     the next K-tile (issued a whole K-tile earlier); behind it the buffer just read is refilled two K-tiles ahead;
+//   * persistent over output tiles: the first two K-tiles of the NEXT output tile are in flight while the epilogue of
+//     the current one runs, so a tile's prologue costs nothing and the K = 768 main loop (12 K-tiles) never restarts
+//     from an empty pipeline.
+// Staging: buffer_load_dwordx4 ... lds (LDS-DMA, 1 KiB per wave-instruction); the LDS image is lane-linear with the
+// XOR swizzle of gemm.hip applied to the per-lane SOURCE offset.  Out-of-range rows are read as zeros by the buffer
+// descriptor's bounds check, so edge tiles need no clamping.
+#include "common.h"
+
+namespace dark {
+
+namespace {
+
+constexpr int PBM = 256, PBN = 256, PBK = 64;
+constexpr int P_OPER = PBM * PBK * 2;      // bytes of one operand tile (32 KiB)
+constexpr int P_STAGE = 2 * P_OPER;        // A + W
+constexpr int P_SMEM = 2 * P_STAGE;        // two K-tiles in LDS: 128 KiB
+constexpr int P_MI = 8, P_NI = 4;          // 16-row / 16-column MFMA tiles per wave (128 x 64)
+
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 v;
+  v[0] = (bf16_t)lo;
+  v[1] = (bf16_t)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float silu_hw(float g) {
+  return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896340736f));
+}
+
+// Two horizontally adjacent 16 x 16 tiles of this lane's final values (row = lane & 15, columns cb + 16t + 4q + e)
+// as ONE 16-byte bf16 store per lane (see store_pair_bf16 in gemm.hip: one permlane16_swap per dword).
+__device__ __forceinline__ void store_pair(const float (&v0)[4], const float (&v1)[4], bf16_t* __restrict__ orow, int cb,
+                                           int ncols, int q) {
+  const uint32_t a_lo = pk_bf16(v0[0], v0[1]), a_hi = pk_bf16(v0[2], v0[3]);
+  const uint32_t b_lo = pk_bf16(v1[0], v1[1]), b_hi = pk_bf16(v1[2], v1[3]);
+  const auto sx = __builtin_amdgcn_permlane16_swap(a_lo, b_lo, false, false);
+  const auto sy = __builtin_amdgcn_permlane16_swap(a_hi, b_hi, false, false);
+  const int c = cb + ((q & 1) ? 16 + 4 * (q - 1) : 4 * q);
+  if (c + 8 <= ncols) *(uint4*)(orow + c) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_p256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                      const float* __restrict__ bias, void* __restrict__ out, int M,
+                                                      int N, int K, int64_t ldo, int tilesM, int tilesN, int ntiles,
+                                                      unsigned a_bytes, unsigned w_bytes) {
+  constexpr int GM = 8;  // row panels per raster group
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int G = gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, G);
+
+  // ---- LDS-DMA: each wave stages 4 pieces (8 rows x 128 B) of A and 4 of W per K-tile.  Piece p covers rows
+  // 8p .. 8p+7; lane l -> row 8p + (l >> 3), physical 16-B chunk l & 7 holds logical chunk (l & 7) ^ ((row >> 1) & 7).
+  // (row >> 1) & 7 = (4p + (l >> 4)) & 7 depends on the piece's parity only -> two per-lane offsets per operand.
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)w_bytes, 0x00020000);
+  const int rib = lane >> 3;  // row inside the piece
+  const unsigned kb = (unsigned)K * 2u;  // bytes per operand row
+  unsigned voff[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int lch = (lane & 7) ^ ((4 * par + (lane >> 4)) & 7);
+    voff[par] = (unsigned)rib * kb + (unsigned)lch * 16u;
+  }
+  // stage K-tile `kt` of the tile at byte offsets (a0, w0) into LDS buffer `buf`
+  auto stage = [&](int buf, unsigned a0, unsigned w0, int kt) {
+    char* base = smem + buf * P_STAGE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = wave * 4 + q;  // piece 0..31 of the operand tile
+      const unsigned so = (unsigned)p * 8u * kb + (unsigned)kt * (PBK * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + p * 1024), 16, voff[q & 1], a0 + so, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = wave * 4 + q;
+      const unsigned so = (unsigned)p * 8u * kb + (unsigned)kt * (PBK * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + P_OPER + p * 1024), 16, voff[q & 1], w0 + so, 0, 0);
+    }
+  };
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int fsw = (frow >> 1) & 7;
+  const int a_rd = (wm * 128 + frow) * 128, w_rd = P_OPER + (wn * 64 + frow) * 128;
+  const int ch0 = ((0 + fq) ^ fsw) << 4, ch1 = ((4 + fq) ^ fsw) << 4;
+
+  auto tile_of = [&](int id, int& tm, int& tn) {
+    const int per_group = GM * tilesN;
+    const int group = id / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(GM, tilesM - first_m);
+    const int rem = id - group * per_group;
+    tn = rem / gsz;
+    tm = first_m + (rem - tn * gsz);
+  };
+
+  const int KT = K / PBK;
+  int gk = 0;  // K-tiles staged so far by this workgroup: K-tile number g lives in LDS buffer g & 1
+  int id = wg;
+  if (id >= ntiles) return;
+  {
+    int tm, tn;
+    tile_of(id, tm, tn);
+    const unsigned a0 = (unsigned)tm * PBM * kb, w0 = (unsigned)tn * PBN * kb;
+    stage(0, a0, w0, 0);
+    stage(1, a0, w0, 1 % KT);  // KT == 1: staged twice, harmless
+  }
+
+  for (; id < ntiles; id += G) {
+    int tm, tn;
+    tile_of(id, tm, tn);
+    const int m0 = tm * PBM, n0 = tn * PBN;
+    const int nid = id + G;
+    unsigned na0 = 0, nw0 = 0;
+    if (nid < ntiles) {
+      int ntm, ntn;
+      tile_of(nid, ntm, ntn);
+      na0 = (unsigned)ntm * PBM * kb;
+      nw0 = (unsigned)ntn * PBN * kb;
+    }
+    const unsigned a0 = (unsigned)m0 * kb, w0 = (unsigned)n0 * kb;
+
+    float4 b4[P_NI];
+    if constexpr (EPI == EPI_BIAS) {
+#pragma unroll
+      for (int ni = 0; ni < P_NI; ++ni) {
+        const int c = n0 + wn * 64 + ni * 16 + 4 * fq;
+        b4[ni].x = c + 0 < N ? bias[c + 0] : 0.f; b4[ni].y = c + 1 < N ? bias[c + 1] : 0.f;
+        b4[ni].z = c + 2 < N ? bias[c + 2] : 0.f; b4[ni].w = c + 3 < N ? bias[c + 3] : 0.f;
+      }
+    }
+
+    f32x4 acc[P_NI][P_MI];
+    bf16x8 fa0[P_MI], fw0[P_NI], fa1[P_MI], fw1[P_NI];
+
+    auto rd = [&](bf16x8 (&fa)[P_MI], bf16x8 (&fw)[P_NI], int buf, int ch) {
+      const char* as = smem + buf * P_STAGE + a_rd + ch;
+      const char* ws = smem + buf * P_STAGE + w_rd + ch;
+#pragma unroll
+      for (int j = 0; j < P_NI; ++j) fw[j] = *(const bf16x8*)(ws + j * 2048);
+#pragma unroll
+      for (int i = 0; i < P_MI; ++i) fa[i] = *(const bf16x8*)(as + i * 2048);
+    };
+    auto mm = [&](const bf16x8 (&fa)[P_MI], const bf16x8 (&fw)[P_NI]) {
+#pragma unroll
+      for (int j = 0; j < P_NI; ++j)
+#pragma unroll
+        for (int i = 0; i < P_MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+    };
+#pragma unroll
+    for (int j = 0; j < P_NI; ++j)
+#pragma unroll
+      for (int i = 0; i < P_MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // K-tile 0 of this tile was issued 16 DMAs ago (8 for it, 8 for K-tile 1), before the previous tile's epilogue
+    // stores: once at most 8 operations are outstanding it has landed (vmcnt retires in order).
+    __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8) (the builtin, so that the compiler's own wait bookkeeping sees it)
+    __builtin_amdgcn_s_barrier();
+    rd(fa0, fw0, gk & 1, ch0);
+    for (int kt = 0; kt < KT; ++kt) {
+      const int buf = (gk + kt) & 1;
+      rd(fa1, fw1, buf, ch1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa0, fw0);
+      __builtin_amdgcn_sched_barrier(0);
+      // my LDS-DMA of the next K-tile has landed, my reads of this one have returned; behind the barrier that holds
+      // for every wave: the next K-tile may be read and this buffer refilled
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < KT) stage(buf, a0, w0, kt + 2);
+      else if (nid < ntiles) stage(buf, na0, nw0, (kt + 2 - KT) % KT);  // the next output tile's K-tiles 0 and 1
+      if (kt + 1 < KT) rd(fa0, fw0, buf ^ 1, ch0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa1, fw1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    gk += KT;
+
+    // ---- epilogue: lane owns row (lane & 15) of each 16-row tile and 4 consecutive columns of each 16-column tile
+#pragma unroll
+    for (int mi = 0; mi < P_MI; ++mi) {
+      const int m = m0 + wm * 128 + mi * 16 + frow;
+      const bool row_ok = m < M;
+      const int64_t mrow = row_ok ? m : 0;
+      if constexpr (EPI == EPI_SWIGLU) {
+        // gate/up rows interleaved in groups of 16: column tiles 2p / 2p+1 are gate / up of 16 output columns
+        float v[2][4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[p][e] = silu_hw(acc[2 * p][mi][e]) * acc[2 * p + 1][mi][e];
+        store_pair(v[0], v[1], (bf16_t*)out + mrow * ldo, (n0 + wn * 64) >> 1, row_ok ? (N >> 1) : 0, fq);
+      } else if constexpr (EPI == EPI_BIAS) {
+#pragma unroll
+        for (int np = 0; np < 2; ++np) {
+          float v[2][4];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int ni = 2 * np + t;
+            v[t][0] = acc[ni][mi][0] + b4[ni].x; v[t][1] = acc[ni][mi][1] + b4[ni].y;
+            v[t][2] = acc[ni][mi][2] + b4[ni].z; v[t][3] = acc[ni][mi][3] + b4[ni].w;
+          }
+          store_pair(v[0], v[1], (bf16_t*)out + mrow * ldo, n0 + wn * 64 + np * 32, row_ok ? N : 0, fq);
+        }
+      } else {  // EPI_F32
+        if (row_ok) {
+          float* orow = (float*)out + mrow * ldo;
+#pragma unroll
+          for (int ni = 0; ni < P_NI; ++ni) {
+            const int c = n0 + wn * 64 + ni * 16 + 4 * fq;
+            if (c + 4 <= N) *(float4*)(orow + c) = make_float4(acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]);
+          }
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Can this shape go to the persistent 256-wide kernel?  (16-byte output pieces, K tiles of 64, 32-bit buffer sizes.)
+bool p256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias) {
+  if (epi != EPI_SWIGLU && epi != EPI_BIAS && epi != EPI_F32) return false;
+  if (K % 64 != 0 || K < 128) return false;
+  const int per16 = epi == EPI_F32 ? 4 : 8;
+  const int ncols = epi == EPI_SWIGLU ? N / 2 : N;
+  if (ldo % per16 != 0 || ncols % per16 != 0 || ((uintptr_t)out & 15) != 0) return false;
+  if (epi == EPI_SWIGLU && N % 32 != 0) return false;
+  if ((int64_t)M * K * 2 >= (1ll << 31) || ((int64_t)N + 256) * K * 2 >= (1ll << 31)) return false;
+  return true;
+}
+
+int launch_gemm_p256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                     int64_t ldo, int w_rows, hipStream_t st) {
+  DARK_CHECK_ARG(p256_supports(epi, M, N, K, ldo, out, bias), "gemm_p256: unsupported shape M=%d N=%d K=%d", M, N, K);
+  const int tilesM = cdiv(M, PBM), tilesN = cdiv(N, PBN);
+  const int ntiles = tilesM * tilesN;
+  int dev = 0, cus = 256;
+  DARK_CHECK_HIP(hipGetDevice(&dev));
+  static std::atomic<int> cu_cache[DARK_MAX_DEVICES] = {};
+  if (dev >= 0 && dev < DARK_MAX_DEVICES) {
+    cus = cu_cache[dev].load(std::memory_order_relaxed);
+    if (cus == 0) {
+      DARK_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      cu_cache[dev].store(cus, std::memory_order_relaxed);
+    }
+  }
+  const int grid = min(ntiles, cus);
+  const unsigned a_bytes = (unsigned)((int64_t)M * K * 2), w_bytes = (unsigned)((int64_t)w_rows * K * 2);
+#define DARK_P256(E)                                                                                               \
+  {                                                                                                                \
+    static SmemOptIn optin;                                                                                        \
+    DARK_TRY(optin.ensure((const void*)gemm_bf16_p256<E>, P_SMEM, st));                                            \
+    hipLaunchKernelGGL((gemm_bf16_p256<E>), dim3(grid), dim3(512), P_SMEM, st, (const bf16_t*)A, (const bf16_t*)W, \
+                       bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes);                         \
+  }
+  if (epi == EPI_SWIGLU) DARK_P256(EPI_SWIGLU)
+  else if (epi == EPI_BIAS) DARK_P256(EPI_BIAS)
+  else DARK_P256(EPI_F32)
+#undef DARK_P256
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+}  // namespace dark

@@ -282,6 +282,9 @@ int dark_prof_read(double* total_ms, double* total_flops, int* launches);
  *        float [M] target logits.  W has rows padded to 128. */
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                   int N, int K, int64_t ldo, void* stream);
+/* Which bf16 GEMM kernel dark_dbg_gemm and the forward use: 0 = the library's choice per shape, 1 = always the
+ * 128-row kernels, 2 = the persistent 256 x 256 kernel wherever it supports the shape (A/B measurements, tests). */
+int dark_dbg_set_gemm_variant(int variant);
 int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                        const uint8_t* key_mask, void* out, int B, int N, int H, int HD, int max_pos,
                        void* stream);
