@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--materialise-noise", action="store_true",
                     help="fill the [M,V] categorical noise with torch instead of computing it in the sampler")
     ap.add_argument("--cpu-sample", type=int, default=48, help="sequences in the CPU-oracle sample")
+    ap.add_argument("--gemm-variant", type=int, default=0, choices=[0, 1, 2],
+                    help="A/B hook: 0 = the library's choice, 1 = 128-row GEMM kernels only, 2 = persistent 256x256 "
+                         "kernel wherever it supports the shape")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on ONE card: every rank uses cuda:0 and the collectives run over gloo (a functional "
                          "rehearsal of the multi-GPU path, not a measurement)")
@@ -97,6 +100,7 @@ def main():
     from dark_amd import DreamConfig, DreamGenerationConfig, DreamModel_length, _hip, dispatch, synth
 
     lib = _hip.load()
+    _hip.check(lib.dark_dbg_set_gemm_variant(args.gemm_variant))
     cfg = DreamConfig(vocab_size=synth.vocab_size(**synth.FB15K237), mask_token_id=synth.MASK,
                       pad_token_id=synth.END)
     weights = synth.make_weights(cfg, seed=0)
