@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, "libdark_hip.so")
 DARK_OK = 0
 DARK_F32, DARK_BF16 = 0, 1
 CONF_PROB, CONF_MARGIN, CONF_NEG_ENTROPY = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
+SHARD_PART_BYTES = 280
 
 
 class LayerWeights(C.Structure):
@@ -63,6 +64,18 @@ SIGNATURES = {
                                           C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
     "dark_philox_exponential": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "dark_final_norm_rows": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "dark_lm_head_shard": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_int64, C.c_void_p]),
+    "dark_shard_row_max": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "dark_shard_partials": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "dark_sample_from_shards": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                          C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64,
+                                          C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dark_sample_rows_indexed": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64,
+                                           C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dark_commit_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_void_p]),
     "dark_denoise_step": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -263,6 +263,53 @@ int dark_lm_head_rows_noalloc(const dark_model_desc* m, const float* hidden, con
   return lm_head_rows(m, hidden, src_rows, 1 << 30, M, ws, kNoAllocScratchBytes, logits, ldl, (hipStream_t)stream);
 }
 
+// ---- vocabulary-sharded head (BASELINE config 3)
+int dark_final_norm_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M, void* out,
+                         void* stream) {
+  DARK_TRY(check_model(m));
+  if (M <= 0) return DARK_OK;
+  DARK_CHECK_ARG(hidden && out, "final_norm_rows: null pointer");
+  return launch_rmsnorm(m->dtype, hidden, m->final_norm, out, src_rows, 1 << 30, M, m->d, m->rms_eps, (hipStream_t)stream);
+}
+
+int dark_lm_head_shard(const dark_model_desc* m, const void* xn, int M, int v0, int Vs, float* logits, int64_t ldl,
+                       void* stream) {
+  DARK_TRY(check_model(m));
+  if (M <= 0) return DARK_OK;
+  DARK_CHECK_ARG(xn && logits, "lm_head_shard: null pointer");
+  DARK_CHECK_ARG(v0 >= 0 && v0 % 128 == 0 && Vs >= 1 && v0 + Vs <= m->vocab && ldl >= Vs,
+                 "lm_head_shard: columns [%d, %d) of a vocabulary of %d (the first column must be a multiple of 128)", v0,
+                 v0 + Vs, m->vocab);
+  const char* w = (const char*)m->lm_head + (size_t)v0 * m->d * esize(m->dtype);
+  return launch_gemm(m->dtype, EPI_F32, xn, w, nullptr, logits, M, Vs, m->d, ldl, (hipStream_t)stream);
+}
+
+int dark_shard_row_max(const float* logits, int64_t ldl, int M, int Vs, float temperature, float* row_max,
+                       void* stream) {
+  return launch_shard_row_max(logits, ldl, M, Vs, temperature, row_max, (hipStream_t)stream);
+}
+
+int dark_shard_partials(const float* logits, int64_t ldl, int M, int Vs, int v0, float temperature,
+                        const float* row_max, void* parts, void* stream) {
+  return launch_shard_partials(logits, ldl, M, Vs, v0, temperature, row_max, parts, (hipStream_t)stream);
+}
+
+int dark_sample_from_shards(const void* parts, int64_t ld_parts, int n_shards, int M, int V, float temperature, float top_p, int top_k,
+                            int conf_mode, const float* row_max, const float* noise, int64_t ldn, uint64_t seed,
+                            uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, uint8_t* fallback,
+                            void* stream) {
+  return launch_sample_from_shards(parts, ld_parts, n_shards, M, V, temperature, top_p, top_k, conf_mode, row_max, noise, ldn,
+                                   seed, offset, nthreads, conf, x0, fallback, (hipStream_t)stream);
+}
+
+int dark_sample_rows_indexed(const float* logits, int64_t ldl, int n, int V, float temperature, float top_p, int top_k,
+                             int conf_mode, const int32_t* row_ids, const float* noise, int64_t ldn, uint64_t seed,
+                             uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, void* stream) {
+  DARK_CHECK_ARG(n <= 0 || row_ids, "sample_rows_indexed: null row_ids");
+  return launch_sample_indexed(logits, ldl, n, V, temperature, top_p, top_k, conf_mode, row_ids, noise, ldn, seed,
+                               offset, nthreads, conf, x0, (hipStream_t)stream);
+}
+
 int dark_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* row_index, int32_t* src_rows,
                    int32_t* count, void* stream) {
   DARK_CHECK_ARG(x && row_index && src_rows && count, "mask_rows: null pointer");

@@ -176,6 +176,18 @@ int launch_sample(const float* logits, int64_t ldl, int M, int V, float temperat
 int launch_sample_philox(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
                          int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
                          uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st);
+// `row_ids` nullable: logits is a compact list of rows row_ids[i] of the [M, V] problem (noise / Philox index / outputs)
+int launch_sample_indexed(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
+                          int conf_mode, const int32_t* row_ids, const float* noise, int64_t ldn, uint64_t seed,
+                          uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st);
+// vocabulary-sharded head (sample.hip)
+int launch_shard_row_max(const float* logits, int64_t ldl, int M, int Vs, float temperature, float* mx, hipStream_t st);
+int launch_shard_partials(const float* logits, int64_t ldl, int M, int Vs, int col0, float temperature,
+                          const float* mx, void* parts, hipStream_t st);
+int launch_sample_from_shards(const void* parts, int64_t ldp, int S, int M, int V, float temperature, float top_p, int top_k,
+                              int conf_mode, const float* mx, const float* noise, int64_t ldn, uint64_t seed,
+                              uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, uint8_t* flags,
+                              hipStream_t st);
 int launch_philox_exponential(uint64_t seed, uint64_t offset, uint32_t nthreads, uint64_t numel, float* out,
                               hipStream_t st);
 int launch_commit(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M,

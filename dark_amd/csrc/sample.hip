@@ -484,7 +484,8 @@ __device__ void list_tail_wave(const uint32_t* cand, const unsigned long long* c
 __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ logits, int64_t ldl, int V,
                                                     float temperature, float top_p, int top_k, int conf_mode,
                                                     const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
-                                                    float* __restrict__ conf, int64_t* __restrict__ x0) {
+                                                    float* __restrict__ conf, int64_t* __restrict__ x0,
+                                                    const int32_t* __restrict__ row_ids) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int vp = (V + 3) & ~3;
   float* row = (float*)smem;
@@ -495,8 +496,10 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   int* cidx = (int*)(cand + CAND_CAP);
   Scratch* s = (Scratch*)(cidx + CAND_CAP);
   const int tid = threadIdx.x;
-  const int m = blockIdx.x;
-  const float* lr = logits + (int64_t)m * ldl;
+  // row_ids (dark_sample_rows_indexed): logits holds a compact list of rows; noise, Philox element index and the
+  // outputs belong to row row_ids[blockIdx.x] of the full [M, V] problem
+  const int m = row_ids ? row_ids[blockIdx.x] : blockIdx.x;
+  const float* lr = logits + (int64_t)blockIdx.x * ldl;
 
   // 1. temperature (generation_utils.py:60-61) and row max
   float mx = -INFINITY;
@@ -769,6 +772,13 @@ int launch_sample(const float* logits, int64_t ldl, int M, int V, float temperat
 int launch_sample_philox(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
                          int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
                          uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st) {
+  return launch_sample_indexed(logits, ldl, M, V, temperature, top_p, top_k, conf_mode, nullptr, noise, ldn, seed, offset,
+                               nthreads, conf, x0, st);
+}
+
+int launch_sample_indexed(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
+                          int conf_mode, const int32_t* row_ids, const float* noise, int64_t ldn, uint64_t seed,
+                          uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st) {
   if (M <= 0) return DARK_OK;
   DARK_CHECK_ARG(V >= 2 && V <= 32768, "sample_rows: V=%d must be in [2, 32768]", V);
   DARK_CHECK_ARG(ldl >= V, "sample_rows: ldl < V");
@@ -784,7 +794,181 @@ int launch_sample_philox(const float* logits, int64_t ldl, int M, int V, float t
   static SmemOptIn optin;
   DARK_TRY(optin.ensure((const void*)sample_kernel, smem, st));
   hipLaunchKernelGGL(sample_kernel, dim3(M), dim3(ST), smem, st, logits, ldl, V, temperature, top_p, top_k,
-                     conf_mode, noise, ldn, pn, conf, x0);
+                     conf_mode, noise, ldn, pn, conf, x0, row_ids);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+// ================================================================== vocabulary-sharded head (BASELINE config 3)
+// The LM head's columns are split over S shards (GPUs); each shard holds logits [M, Vs] for its column range and
+// never sends them anywhere.  What the sampler needs from a row crosses shards in two small exchanges:
+//   1. the row maximum of logits / T  (max is exact and associative: all-reduce of M floats);
+//   2. per shard, relative to that GLOBAL maximum: the fixed-point probability mass of its columns (integers: sums
+//      are exact in any order), and the few elements within HEAD_RANGE of the maximum (key, mass, vocabulary id).
+// The owner of the row adds the masses, concatenates the candidates and finishes exactly as sample_kernel's head
+// path does (list_tail_wave: crossing, kept set, softmax, confidence, Philox draw) -- bit-identical to the unsharded
+// sampler.  Rows whose head set does not hold top_p of the mass, or holds more than 64 elements (flat rows), are
+// flagged; the caller gathers those rows' logits and runs dark_sample_rows_indexed on them.
+constexpr int SHARD_CAP = DARK_SHARD_CAND_CAP;  // candidates a shard can report per row
+struct ShardPart {
+  unsigned long long Z, hl;  // mass of the shard's columns; mass of the reported candidates
+  int n, pad;                // candidates found (> SHARD_CAP: not all could be reported)
+  unsigned long long fx[SHARD_CAP];
+  uint32_t key[SHARD_CAP];
+  int idx[SHARD_CAP];
+};
+static_assert(sizeof(ShardPart) == DARK_SHARD_PART_BYTES, "ShardPart layout is part of the C ABI");
+
+__global__ __launch_bounds__(256) void shard_row_max_kernel(const float* __restrict__ logits, int64_t ldl, int Vs,
+                                                            float temperature, float* __restrict__ mx) {
+  __shared__ float wmax[4];
+  const float* lr = logits + (int64_t)blockIdx.x * ldl;
+  float v = -INFINITY;
+  for (int i = threadIdx.x; i < Vs; i += 256) {
+    float l = lr[i];
+    if (temperature > 0.f) l = l / temperature;  // the sampler's own operation order (generation_utils.py:60-61)
+    v = fmaxf(v, l);
+  }
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) mx[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+}
+
+__global__ __launch_bounds__(256) void shard_partials_kernel(const float* __restrict__ logits, int64_t ldl, int Vs,
+                                                             int col0, float temperature,
+                                                             const float* __restrict__ mx_all,
+                                                             ShardPart* __restrict__ parts) {
+  __shared__ ShardPart sp;
+  __shared__ unsigned long long wsum[2][4];
+  const int tid = threadIdx.x;
+  const float* lr = logits + (int64_t)blockIdx.x * ldl;
+  const float mx = mx_all[blockIdx.x];
+  if (tid == 0) sp.n = 0;
+  __syncthreads();
+  unsigned long long zl = 0, hl = 0;
+  for (int i = tid; i < Vs; i += 256) {
+    float l = lr[i];
+    if (temperature > 0.f) l = l / temperature;
+    const unsigned long long fx = mass_fx(l, mx);
+    zl += fx;
+    if (l - mx > -HEAD_RANGE) {
+      const int slot = atomicAdd(&sp.n, 1);
+      if (slot < SHARD_CAP) { sp.key[slot] = fkey(l); sp.fx[slot] = fx; sp.idx[slot] = col0 + i; hl += fx; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { zl += __shfl_xor(zl, o, 64); hl += __shfl_xor(hl, o, 64); }
+  if ((tid & 63) == 0) { wsum[0][tid >> 6] = zl; wsum[1][tid >> 6] = hl; }
+  __syncthreads();
+  ShardPart* out = parts + blockIdx.x;
+  if (tid == 0) {
+    out->Z = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+    out->hl = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
+    out->n = sp.n;
+    out->pad = 0;
+  }
+  if (tid < SHARD_CAP) {
+    const bool have = tid < sp.n;
+    out->key[tid] = have ? sp.key[tid] : 0u;
+    out->fx[tid] = have ? sp.fx[tid] : 0ull;
+    out->idx[tid] = have ? sp.idx[tid] : 0;
+  }
+}
+
+// One wave per row: merge the S shard records of row m (parts[s * ldp + m]) and finish the row, or flag it.
+__global__ __launch_bounds__(256) void sample_from_shards_kernel(const ShardPart* __restrict__ parts, int64_t ldp, int S, int M, int V,
+                                                                 float temperature, float top_p, int top_k,
+                                                                 int conf_mode, const float* __restrict__ mx_all,
+                                                                 const float* __restrict__ noise, int64_t ldn,
+                                                                 PhiloxNoise pn, float* __restrict__ conf,
+                                                                 int64_t* __restrict__ x0,
+                                                                 uint8_t* __restrict__ flags) {
+  __shared__ unsigned long long cfx_s[4][64];
+  __shared__ uint32_t cand_s[4][64];
+  __shared__ int cidx_s[4][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + w;
+  if (m >= M) return;  // wave-uniform
+  const bool nucleus = top_p >= 0.f && top_p < 1.f && !(top_k > 0 && top_k < V);
+  unsigned long long Z = 0, hl = 0;
+  int c = 0;
+  bool over = false;
+  for (int s0 = 0; s0 < S; s0 += 64) {  // S <= 64 in practice: one pass
+    const int s = s0 + lane;
+    unsigned long long z1 = 0, h1 = 0;
+    int n1 = 0;
+    if (s < S) {
+      const ShardPart* p = parts + (int64_t)s * ldp + m;
+      z1 = p->Z; h1 = p->hl; n1 = p->n;
+    }
+    const bool ov = n1 > SHARD_CAP;
+    over |= __ballot(ov) != 0ull;
+    // exclusive prefix of the candidate counts: where this shard's candidates go in the merged list
+    int inc = ov ? 0 : n1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    const int base = c + inc - (ov ? 0 : n1);
+    if (s < S && !ov && base + n1 <= 64) {
+      const ShardPart* p = parts + (int64_t)s * ldp + m;
+      for (int i = 0; i < n1; ++i) {
+        cand_s[w][base + i] = p->key[i];
+        cfx_s[w][base + i] = p->fx[i];
+        cidx_s[w][base + i] = p->idx[i];
+      }
+    }
+    c += __shfl(inc, 63, 64);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { z1 += __shfl_xor(z1, o, 64); h1 += __shfl_xor(h1, o, 64); }
+    Z += z1;
+    hl += h1;
+  }
+  const unsigned long long T = (unsigned long long)((double)top_p * (double)Z);  // floor, as nucleus_crossing
+  if (!nucleus || over || c > 64 || !(hl > T)) {
+    if (lane == 0) flags[m] = 1;
+    return;
+  }
+  if (lane == 0) flags[m] = 0;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list was written by other lanes of this wave
+  list_tail_wave(cand_s[w], cfx_s[w], cidx_s[w], c, T, mx_all[m], V, temperature, conf_mode,
+                 noise ? noise + (int64_t)m * ldn : nullptr, pn, (unsigned long long)m * V, lane, conf + m, x0 + m);
+}
+
+int launch_shard_row_max(const float* logits, int64_t ldl, int M, int Vs, float temperature, float* mx,
+                         hipStream_t st) {
+  if (M <= 0) return DARK_OK;
+  DARK_CHECK_ARG(logits && mx && Vs >= 1 && ldl >= Vs, "shard_row_max: bad argument");
+  hipLaunchKernelGGL(shard_row_max_kernel, dim3(M), dim3(256), 0, st, logits, ldl, Vs, temperature, mx);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+int launch_shard_partials(const float* logits, int64_t ldl, int M, int Vs, int col0, float temperature,
+                          const float* mx, void* parts, hipStream_t st) {
+  if (M <= 0) return DARK_OK;
+  DARK_CHECK_ARG(logits && mx && parts && Vs >= 1 && ldl >= Vs && col0 >= 0, "shard_partials: bad argument");
+  hipLaunchKernelGGL(shard_partials_kernel, dim3(M), dim3(256), 0, st, logits, ldl, Vs, col0, temperature, mx,
+                     (ShardPart*)parts);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+int launch_sample_from_shards(const void* parts, int64_t ldp, int S, int M, int V, float temperature, float top_p, int top_k,
+                              int conf_mode, const float* mx, const float* noise, int64_t ldn, uint64_t seed,
+                              uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, uint8_t* flags,
+                              hipStream_t st) {
+  if (M <= 0) return DARK_OK;
+  DARK_CHECK_ARG(parts && mx && conf && x0 && flags && S >= 1 && S <= 4096 && ldp >= M, "sample_from_shards: bad argument");
+  DARK_CHECK_ARG(V >= 2 && conf_mode >= 0 && conf_mode <= 2 && temperature >= 0.f, "sample_from_shards: bad argument");
+  DARK_CHECK_ARG(!(temperature > 0.f) || nthreads > 0 || (noise && ldn >= V),
+                 "sample_from_shards: temperature > 0 needs noise [M,V] or a Philox state");
+  const PhiloxNoise pn{seed, offset, nthreads};
+  hipLaunchKernelGGL(sample_from_shards_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const ShardPart*)parts, ldp, S, M, V,
+                     temperature, top_p, top_k, conf_mode, mx, noise, ldn, pn, conf, x0, flags);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }

@@ -100,14 +100,17 @@ def global_mask_count(local_count: torch.Tensor, local_batch: int, group=None) -
 @torch.no_grad()
 def generate_sharded(model, inputs: torch.Tensor, generation_config=None, *, group=None, gather: bool = True,
                      exact_ragged_k: bool = False, attention_mask: Optional[torch.Tensor] = None,
-                     **kwargs) -> torch.Tensor:
+                     shard_head: bool = False, **kwargs) -> torch.Tensor:
     """``model.diffusion_generate`` over this rank's row block of `inputs` (same tensor on every rank),
     then, if `gather`, an all_gather of the `[B_local, N]` sequences so every rank returns `[B, N]`.
 
     RNG: each rank draws from its own device generator, so stochastic parity (temperature > 0) is defined per
     shard: same seed + same rows => same result as an unsharded call on those rows alone.
     `exact_ragged_k`: all-reduce the mask count every step (only matters when rows carry different numbers of
-    masks)."""
+    masks).
+    `shard_head`: BASELINE config 3 -- split the LM head's vocabulary columns over the ranks of the group
+    (vocab_shard.ShardedHead: all-gather of hidden rows, all-reduce of row maxima, all-to-all of per-shard candidate
+    records); results are bit-identical to the unsharded head.  Every rank must hold at least one row."""
     world, rank = _world(group)
     total = inputs.shape[0]
     lo, hi = shard_bounds(total, world, rank)
@@ -119,6 +122,11 @@ def generate_sharded(model, inputs: torch.Tensor, generation_config=None, *, gro
         if total < world:
             raise ValueError("exact_ragged_k needs at least one row per rank (every rank joins the per-step all-reduce)")
         kwargs["_count_reduce"] = lambda cnt, b: global_mask_count(cnt, b, group)
+    if shard_head and world > 1:
+        if total < world:
+            raise ValueError("shard_head needs at least one row per rank (every rank joins the per-step exchanges)")
+        from .vocab_shard import ShardedHead
+        kwargs["_sharded_head"] = ShardedHead(model, group)
     if hi > lo:
         local = model.diffusion_generate(inputs[lo:hi], generation_config=generation_config, **kwargs)
     else:

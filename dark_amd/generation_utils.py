@@ -138,6 +138,7 @@ class _LoopCtx:
     state_hook: Optional[Callable] = None    # parity tests: teacher forcing, (step, x) -> x
     count_reduce: Optional[Callable] = None  # dispatch.generate_sharded(exact_ragged_k=True)
     trace: Optional[dict] = None             # parity tests: receives per-step k / conf / x0
+    head: Optional[Any] = None               # vocab_shard.ShardedHead: head + sampling split over a process group
 
 
 class DreamGenerationMixin:
@@ -223,7 +224,7 @@ class DreamGenerationMixin:
                        lazy_noise=bool(kwargs.pop("lazy_noise", True)),
                        noise_fn=kwargs.pop("_noise_fn", None), rand_fn=kwargs.pop("_rand_fn", None),
                        state_hook=kwargs.pop("_state_hook", None), count_reduce=kwargs.pop("_count_reduce", None),
-                       trace=kwargs.pop("_trace", None))
+                       trace=kwargs.pop("_trace", None), head=kwargs.pop("_sharded_head", None))
 
         assert inputs is not None
         input_ids = inputs
@@ -299,6 +300,9 @@ class DreamGenerationMixin:
         tokens_hook = generation_tokens_hook_func or (lambda step, x, logits: x)
         logits_hook = generation_logits_hook_func or (lambda step, x, logits: logits)
         fast = default_hooks and alg != "origin" and (alg_temp is None or alg_temp == 0) and not think
+        if ctx.head is not None and not fast:
+            raise NotImplementedError("the vocabulary-sharded head serves the confidence algorithms with alg_temp in "
+                                      "{None, 0} and default hooks")
         # the reference filters iff `top_p is not None and top_p < 1` (:62): 0 keeps the top-1 token only; < 0 = off
         top_p_f = max(float(top_p), 0.0) if (top_p is not None and top_p < 1) else -1.0
         top_k_i = int(min(top_k, self.config.vocab_size)) if top_k is not None else 0
@@ -368,7 +372,9 @@ class DreamGenerationMixin:
         B, N = x.shape
         V = self.config.vocab_size
         noise_fn, trace = ctx.noise_fn, ctx.trace
-        skip = ctx.skip_noop and trace is None
+        # with a sharded head every rank must join every step's collectives: nothing is skipped
+        lockstep = ctx.head is not None and ctx.head.distributed
+        skip = ctx.skip_noop and trace is None and not lockstep
         if not (skip and st.hidden_valid):
             st.mask_rows(x, mask_id)              # row_index / src_rows / count, then async count read-back
             # enqueued before the host waits for the count: everything up to the last layer's attention; the rest of
@@ -381,23 +387,26 @@ class DreamGenerationMixin:
         if trace is not None:
             trace.setdefault("k", []).append(k)
             trace.setdefault("M", []).append(M)
-        if M == 0:
+        if M == 0 and not lockstep:
             return
         noise = philox = None
-        if temperature > 0:
+        if temperature > 0 and M > 0:
             if noise_fn is None and ctx.lazy_noise:
                 philox = philox_fill_plan(x.device, M * V)
             else:
                 noise = self._draw_noise(step, M, V, x.device, noise_fn)
         if skip and k == 0:
             return  # nothing is committed: the draw above was this step's only effect
-        if not st.rows_valid:
+        if not st.rows_valid and M > 0:
             st.forward_rows(M)
-        conf, x0 = st.head_and_sample(M, temperature, top_p, top_k, conf_mode, noise, philox)
+        if ctx.head is not None:
+            conf, x0 = ctx.head.head_and_sample(st, M, temperature, top_p, top_k, conf_mode, noise, philox)
+        else:
+            conf, x0 = st.head_and_sample(M, temperature, top_p, top_k, conf_mode, noise, philox)
         if trace is not None:
             trace.setdefault("confidence", []).append(conf.clone())
             trace.setdefault("x0", []).append(x0.clone())
-        if k > 0:
+        if k > 0 and M > 0:
             st.commit(x, mask_id, M, conf, x0, k)
             st.hidden_valid = False
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DARK_HIP_ABI_VERSION 2
+#define DARK_HIP_ABI_VERSION 3
 
 #define DARK_OK 0
 #define DARK_ERR_ARG 1         /* bad shape / pointer / unsupported size */
@@ -165,6 +165,45 @@ int dark_sample_rows_philox(const float* logits, int64_t ldl, int M, int V, floa
                             void* stream);
 int dark_philox_exponential(uint64_t seed, uint64_t offset, uint32_t nthreads, uint64_t numel, float* out,
                             void* stream);
+
+/* ---- vocabulary-sharded LM head + sampler (BASELINE config 3: "logit head vocabulary-sharded with an RCCL
+ * all-gather of per-shard top-k").  The head's columns (modeling_dream_length.py:809) are split over S shards, one
+ * per GPU; a shard's logits [M, Vs] never leave it.  Per step the shards exchange (dark_amd/dispatch.py):
+ *   the normalised hidden rows of every rank's masked positions (all-gather of [M, d]);
+ *   the row maxima of logits / T (all-reduce MAX of [M] floats);
+ *   one DARK_SHARD_PART_BYTES record per row and shard: fixed-point mass of the shard's columns relative to the
+ *   GLOBAL row maximum (integers: sums are exact in any order) and the <= DARK_SHARD_CAND_CAP elements within 6.0 of
+ *   it as (order key, mass, vocabulary id).
+ * dark_sample_from_shards merges the S records of a row and finishes it exactly as dark_sample_rows does on peaked
+ * rows: conf / x0 are BIT-IDENTICAL to the unsharded sampler (same generator stream when Philox noise is used).  Rows
+ * whose candidates do not hold top_p of the mass, hold more than 64 elements, or overflow a shard's record (flat
+ * rows; also every row when the nucleus filter is off or top_k is on) get fallback[m] = 1 and no result: gather
+ * their logits and run dark_sample_rows_indexed.
+ *   dark_final_norm_rows: out [M, d] model dtype = final RMSNorm (:721) of hidden[src_rows[m]] (NULL = rows 0..M-1)
+ *   dark_lm_head_shard: logits [M, ldl] fp32 = xn [M, d] x lm_head[v0 : v0 + Vs]^T; v0 must be a multiple of 128
+ *   dark_shard_row_max: row_max[m] = max_v(logits[m, v] / T) over the shard's Vs columns (T = 0: no division)
+ *   dark_shard_partials: parts[m] for the shard whose first column is v0, relative to row_max (the GLOBAL maxima)
+ *   dark_sample_from_shards: parts [n_shards, ld_parts] records (shard-major, ld_parts >= M rows per shard); noise/seed/offset/nthreads as in
+ *     dark_sample_rows / dark_sample_rows_philox, for the owner's own [M, V] fill
+ *   dark_sample_rows_indexed: dark_sample_rows(_philox) on a compact list of n rows: logits [n, ldl] is row
+ *     row_ids[i] of the [M, V] problem; noise row, Philox element index and conf / x0 slot are those of row_ids[i]. */
+#define DARK_SHARD_CAND_CAP 16
+#define DARK_SHARD_PART_BYTES 280
+int dark_final_norm_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M, void* out,
+                         void* stream);
+int dark_lm_head_shard(const dark_model_desc* m, const void* xn, int M, int v0, int Vs, float* logits, int64_t ldl,
+                       void* stream);
+int dark_shard_row_max(const float* logits, int64_t ldl, int M, int Vs, float temperature, float* row_max,
+                       void* stream);
+int dark_shard_partials(const float* logits, int64_t ldl, int M, int Vs, int v0, float temperature,
+                        const float* row_max, void* parts, void* stream);
+int dark_sample_from_shards(const void* parts, int64_t ld_parts, int n_shards, int M, int V, float temperature, float top_p, int top_k,
+                            int conf_mode, const float* row_max, const float* noise, int64_t ldn, uint64_t seed,
+                            uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, uint8_t* fallback,
+                            void* stream);
+int dark_sample_rows_indexed(const float* logits, int64_t ldl, int n, int V, float temperature, float top_p, int top_k,
+                             int conf_mode, const int32_t* row_ids, const float* noise, int64_t ldn, uint64_t seed,
+                             uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, void* stream);
 
 /* Confidence-ranked commit (generation_utils.py:522-534 with alg_temp in {None, 0}):
  * per row, the k positions with the largest confidence (non-masked positions count as -inf, ties

@@ -40,10 +40,36 @@ def gen_config():
                                  eos_token_id=synth.END, sep_token_id=synth.SEP, max_length=46)
 
 
+def shard_mode(rank, world, prefix):
+    """Data-parallel rows + the vocabulary-sharded head (BASELINE config 3) against the plain data-parallel run."""
+    from dark_amd.vocab_shard import ShardedHead
+    m = build()
+    ids = synth.make_inputs(12, "ded", seed=23).to("cuda:0")
+    kw = dict(steps=10, temperature=0.5, alg="entropy", alg_temp=0, top_p=0.9)
+    res = {}
+    torch.manual_seed(300 + rank)
+    res["plain"] = dispatch.generate_sharded(m, ids, gen_config(), **kw).cpu()
+    torch.manual_seed(300 + rank)
+    head = ShardedHead(m, None)
+    lo, hi = dispatch.shard_bounds(12, world, rank)
+    local = m.diffusion_generate(ids[lo:hi], generation_config=gen_config(), _sharded_head=head, **kw)
+    res["sharded"] = dispatch.gather_rows(local, 12).cpu()
+    torch.manual_seed(300 + rank)
+    again = dispatch.generate_sharded(m, ids, gen_config(), shard_head=True, **kw).cpu()
+    assert torch.equal(again, res["sharded"])
+    res["fallback"] = (head.fallback_rows, head.rows)
+    torch.save(res, f"{prefix}.rank{rank}.pt")
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
     torch.cuda.set_device(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "shard":
+        shard_mode(rank, world, sys.argv[1])
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     m = build()
     rag = ragged_inputs().to("cuda:0")
     res = {}

@@ -23,13 +23,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(world, prefix):
+def _run_ranks(world, prefix, mode="dp"):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dispatch_worker.py"), prefix], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dispatch_worker.py"), prefix, mode], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, p in enumerate(procs):
