@@ -78,6 +78,10 @@ SIGNATURES = {
                                            C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dark_commit_topk": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_void_p]),
+    "dark_commit_sampled": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "dark_scatter_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_void_p]),
     "dark_denoise_step": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),

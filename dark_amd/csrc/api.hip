@@ -342,6 +342,19 @@ int dark_commit_topk(int64_t* x, int B, int N, int64_t mask_id, const int32_t* r
   return launch_commit(x, B, N, mask_id, row_index, M, conf, x0, k, (hipStream_t)stream);
 }
 
+int dark_commit_sampled(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M, const float* conf,
+                        const int64_t* x0, int k, float alg_temp, const float* exp_noise, void* stream) {
+  DARK_CHECK_ARG(x && (M == 0 || (row_index && conf && x0)), "commit_sampled: null pointer");
+  DARK_CHECK_ARG(alg_temp > 0.f && exp_noise, "commit_sampled: needs alg_temp > 0 and the [B,N] Exp(1) draws");
+  return launch_commit(x, B, N, mask_id, row_index, M, conf, x0, k, (hipStream_t)stream, alg_temp, exp_noise);
+}
+
+int dark_scatter_tokens(int64_t* x, int B, int N, const int32_t* row_index, int M, const int64_t* sel,
+                        const int64_t* tokens, int n, void* stream) {
+  DARK_CHECK_ARG(B > 0 && N > 0, "scatter_tokens: bad B=%d N=%d", B, N);
+  return launch_scatter_tokens(x, (int64_t)B * N, row_index, M, sel, tokens, n, (hipStream_t)stream);
+}
+
 int dark_denoise_step(const dark_model_desc* m, int64_t* x, const int32_t* pos, const uint8_t* key_mask, int B, int N,
                       int M, int64_t mask_id, float temperature, float top_p, int top_k, int conf_mode,
                       const float* noise, int k, void* workspace, size_t workspace_bytes, void* stream) {

@@ -190,7 +190,11 @@ int launch_sample_from_shards(const void* parts, int64_t ldp, int S, int M, int 
                               hipStream_t st);
 int launch_philox_exponential(uint64_t seed, uint64_t offset, uint32_t nthreads, uint64_t numel, float* out,
                               hipStream_t st);
+// alg_temp > 0: multinomial ranking with the [B,N] Exp(1) draws `qnoise` (generation_utils.py:527-530)
 int launch_commit(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M,
-                  const float* conf, const int64_t* x0, int k, hipStream_t st);
+                  const float* conf, const int64_t* x0, int k, hipStream_t st, float alg_temp = 0.f,
+                  const float* qnoise = nullptr);
+int launch_scatter_tokens(int64_t* x, int64_t total, const int32_t* row_index, int M, const int64_t* sel,
+                          const int64_t* tokens, int n, hipStream_t st);
 
 }  // namespace dark

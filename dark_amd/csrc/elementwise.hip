@@ -306,7 +306,8 @@ template <int E>  // positions per lane, N <= 64*E
 __global__ __launch_bounds__(256) void commit_kernel(int64_t* __restrict__ x, int B, int N, int64_t mask_id,
                                                      const int32_t* __restrict__ row_index, int M,
                                                      const float* __restrict__ conf,
-                                                     const int64_t* __restrict__ x0, int k) {
+                                                     const int64_t* __restrict__ x0, int k, float alg_temp,
+                                                     const float* __restrict__ qnoise) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;
   // first m with row_index[m] >= b*N (binary search; row_index is ascending)
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(256) void commit_kernel(int64_t* __restrict__ x, in
     if (row_index[mid] < key) lo = mid + 1; else hi = mid;
   }
   int m_next = lo;
-  uint32_t c[E];  // order_key of the confidence: NaN ranks first, as in torch.topk
+  uint32_t c[E];  // order_key of the ranking value: NaN ranks first, as in torch.topk
+  float cf[E];
   int64_t tok[E];
   bool msk[E];
 #pragma unroll
@@ -328,14 +330,44 @@ __global__ __launch_bounds__(256) void commit_kernel(int64_t* __restrict__ x, in
     const unsigned long long bal = __ballot(is_mask);
     const int rank = __popcll(bal & ((1ull << lane) - 1ull));
     msk[e] = is_mask;
-    c[e] = order_key(-INFINITY);
+    cf[e] = -INFINITY;
     tok[e] = mask_id;
     if (is_mask) {
-      c[e] = order_key(conf[m_next + rank]);
+      cf[e] = conf[m_next + rank];
       tok[e] = x0[m_next + rank];
     }
     m_next += __popcll(bal);  // (positions j >= N are never selected and never counted below)
   }
+  if (alg_temp > 0.f) {
+    // generation_utils.py:527-530: p = softmax(full_confidence / alg_temp) over the row, then
+    // torch.multinomial(p, k) WITHOUT replacement, which ATen evaluates as topk(p / q, k) with q ~ Exp(1) drawn as
+    // one `exponential_` fill of [B, N] (aten/src/ATen/native/Distributions.cpp, multinomial fast path).  qnoise is
+    // that fill.  Unmasked positions have p = 0 and rank last; a row with no masked position at all makes the
+    // reference raise (NaN probabilities) -- here it re-masks its first k positions like the deterministic branch.
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      cf[e] = cf[e] / alg_temp;
+      if (e * 64 + lane < N) mx = fmaxf(mx, cf[e]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const bool valid = e * 64 + lane < N;
+      cf[e] = (valid && mx != -INFINITY) ? expf(cf[e] - mx) : 0.f;
+      sum += cf[e];
+    }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = e * 64 + lane;
+      const float p = sum > 0.f ? cf[e] / sum : 0.f;
+      cf[e] = j < N ? p / qnoise[(int64_t)b * N + j] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) c[e] = order_key(cf[e]);
   // rank of every position in (confidence desc, index asc) order
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -355,18 +387,42 @@ __global__ __launch_bounds__(256) void commit_kernel(int64_t* __restrict__ x, in
 }
 
 int launch_commit(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M,
-                  const float* conf, const int64_t* x0, int k, hipStream_t st) {
+                  const float* conf, const int64_t* x0, int k, hipStream_t st, float alg_temp, const float* qnoise) {
   DARK_CHECK_ARG(B > 0 && N > 0 && N <= 256, "commit: N=%d must be in [1,256]", N);
   DARK_CHECK_ARG(M >= 0 && k >= 0, "commit: bad M=%d k=%d", M, k);
+  DARK_CHECK_ARG(!(alg_temp > 0.f) || qnoise, "commit: alg_temp > 0 needs the [B,N] Exp(1) draws");
   if (k == 0) return DARK_OK;
   if (k > N) k = N;
   const dim3 grid(cdiv(B, 4)), block(256);
   if (N <= 64)
-    hipLaunchKernelGGL(commit_kernel<1>, grid, block, 0, st, x, B, N, mask_id, row_index, M, conf, x0, k);
+    hipLaunchKernelGGL(commit_kernel<1>, grid, block, 0, st, x, B, N, mask_id, row_index, M, conf, x0, k, alg_temp, qnoise);
   else if (N <= 128)
-    hipLaunchKernelGGL(commit_kernel<2>, grid, block, 0, st, x, B, N, mask_id, row_index, M, conf, x0, k);
+    hipLaunchKernelGGL(commit_kernel<2>, grid, block, 0, st, x, B, N, mask_id, row_index, M, conf, x0, k, alg_temp, qnoise);
   else
-    hipLaunchKernelGGL(commit_kernel<4>, grid, block, 0, st, x, B, N, mask_id, row_index, M, conf, x0, k);
+    hipLaunchKernelGGL(commit_kernel<4>, grid, block, 0, st, x, B, N, mask_id, row_index, M, conf, x0, k, alg_temp, qnoise);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+// alg = 'origin' (generation_utils.py:505-510): x[mask_index] = x0 where x0 is MASK except at the rows that drew
+// `rand < p_transfer`; only those rows were sampled.  x[row_index[sel[i]]] = tokens[i].
+__global__ __launch_bounds__(256) void scatter_tokens_kernel(int64_t* __restrict__ x, int64_t total,
+                                                             const int32_t* __restrict__ row_index, int M,
+                                                             const int64_t* __restrict__ sel,
+                                                             const int64_t* __restrict__ tokens, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t m = sel[i];
+  if (m < 0 || m >= M) return;
+  const int64_t f = row_index[m];
+  if (f >= 0 && f < total) x[f] = tokens[i];
+}
+
+int launch_scatter_tokens(int64_t* x, int64_t total, const int32_t* row_index, int M, const int64_t* sel,
+                          const int64_t* tokens, int n, hipStream_t st) {
+  if (n <= 0) return DARK_OK;
+  DARK_CHECK_ARG(x && row_index && sel && tokens && M > 0, "scatter_tokens: bad argument");
+  hipLaunchKernelGGL(scatter_tokens_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, total, row_index, M, sel, tokens, n);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }

@@ -135,6 +135,7 @@ class _LoopCtx:
     lazy_noise: bool = True         # Exp(1) draws evaluated inside the sampler from torch's Philox stream
     noise_fn: Optional[Callable] = None      # parity tests: inject the Exp(1) draws, (step, M, V) -> [M, V]
     rand_fn: Optional[Callable] = None       # parity tests: inject alg='origin' uniforms, (step, M) -> [M]
+    rank_noise_fn: Optional[Callable] = None  # parity tests: inject multinomial's Exp(1) draws, (step, B, N) -> [B, N]
     state_hook: Optional[Callable] = None    # parity tests: teacher forcing, (step, x) -> x
     count_reduce: Optional[Callable] = None  # dispatch.generate_sharded(exact_ragged_k=True)
     trace: Optional[dict] = None             # parity tests: receives per-step k / conf / x0
@@ -223,6 +224,7 @@ class DreamGenerationMixin:
         ctx = _LoopCtx(skip_noop=bool(kwargs.pop("skip_noop_steps", True)),
                        lazy_noise=bool(kwargs.pop("lazy_noise", True)),
                        noise_fn=kwargs.pop("_noise_fn", None), rand_fn=kwargs.pop("_rand_fn", None),
+                       rank_noise_fn=kwargs.pop("_rank_noise_fn", None),
                        state_hook=kwargs.pop("_state_hook", None), count_reduce=kwargs.pop("_count_reduce", None),
                        trace=kwargs.pop("_trace", None), head=kwargs.pop("_sharded_head", None))
 
@@ -299,10 +301,11 @@ class DreamGenerationMixin:
         default_hooks = generation_tokens_hook_func is None and generation_logits_hook_func is None
         tokens_hook = generation_tokens_hook_func or (lambda step, x, logits: x)
         logits_hook = generation_logits_hook_func or (lambda step, x, logits: logits)
-        fast = default_hooks and alg != "origin" and (alg_temp is None or alg_temp == 0) and not think
-        if ctx.head is not None and not fast:
-            raise NotImplementedError("the vocabulary-sharded head serves the confidence algorithms with alg_temp in "
-                                      "{None, 0} and default hooks")
+        # Native loop for every algorithm; only user hooks and think_sample need the materialised [B, N, V] logits
+        fast = default_hooks and not think
+        rank_temp = float(alg_temp) if (alg_temp is not None and alg_temp != 0) else 0.0
+        if ctx.head is not None and (not fast or alg == "origin"):
+            raise NotImplementedError("the vocabulary-sharded head serves the confidence algorithms with default hooks")
         # the reference filters iff `top_p is not None and top_p < 1` (:62): 0 keeps the top-1 token only; < 0 = off
         top_p_f = max(float(top_p), 0.0) if (top_p is not None and top_p < 1) else -1.0
         top_k_i = int(min(top_k, self.config.vocab_size)) if top_k is not None else 0
@@ -313,9 +316,11 @@ class DreamGenerationMixin:
         for i in range(steps):
             t, s = timesteps[i], timesteps[i + 1]
             last = i == steps - 1
-            if fast:
+            if fast and alg == "origin":
+                self._step_origin(st, x, pos, key_mask, mask_token_id, temperature, top_p_f, top_k_i, t, s, last, i, ctx)
+            elif fast:
                 self._step_fast(st, x, pos, key_mask, mask_token_id, temperature, top_p_f, top_k_i, _CONF_MODE[alg],
-                                t, s, last, i, ctx)
+                                t, s, last, i, ctx, rank_temp)
             else:
                 # think_sample steps (generation_utils.py:490-491, :411-432): `check_and_select` forwards 4 identical
                 # copies of every row with arange positions (`calculate_results`, :369-372), resamples them twice and
@@ -366,9 +371,41 @@ class DreamGenerationMixin:
             return q
         return torch.empty((M, V), device=device, dtype=torch.float32).exponential_()
 
+    def _step_origin(self, st, x, pos, key_mask, mask_id, temperature, top_p, top_k, t, s, last, step,
+                     ctx: _LoopCtx) -> None:
+        """One iteration of generation_utils.py:488-510 for alg='origin', on device: every masked position draws
+        `rand < 1 - s/t` (torch's generator, as the reference), the positions that pass are sampled -- the last
+        layer's tail, the head and the sampler run for those rows ONLY -- and written into x; the others stay MASK."""
+        B, N = x.shape
+        V = self.config.vocab_size
+        st.mask_rows(x, mask_id)
+        st.forward_begin(x, pos, key_mask)
+        st.hidden_valid = False
+        M = st.wait_count()
+        if M == 0:
+            return
+        p_transfer = 1 - s / t if not last else 1
+        u = torch.rand(M, device=x.device) if ctx.rand_fn is None else ctx.rand_fn(step, M).to(x.device)
+        transfer = u < (p_transfer.to(x.device) if isinstance(p_transfer, torch.Tensor) else p_transfer)
+        sel = transfer.nonzero(as_tuple=False).flatten()   # (the reference syncs here too: boolean indexing, :509)
+        n = int(sel.numel())
+        if n == 0:
+            return
+        rows = st.src_rows[:M][sel].contiguous()
+        logits = st.head_rows(None, n, st.forward_rows(n, rows))
+        noise = philox = None
+        if temperature > 0:
+            if ctx.noise_fn is None and ctx.lazy_noise:
+                philox = philox_fill_plan(x.device, n * V)
+            else:
+                noise = self._draw_noise(step, n, V, x.device, ctx.noise_fn)
+        _, x0 = st.sample_into(logits, n, temperature, top_p, top_k, _hip.CONF_PROB, noise, philox)
+        st.scatter(x, M, sel, x0, n)
+
     def _step_fast(self, st, x, pos, key_mask, mask_id, temperature, top_p, top_k, conf_mode, t, s, last, step,
-                   ctx: _LoopCtx) -> None:
-        """One iteration of generation_utils.py:488-540 for the confidence algorithms, fully on device."""
+                   ctx: _LoopCtx, rank_temp: float = 0.0) -> None:
+        """One iteration of generation_utils.py:488-540 for the confidence algorithms, fully on device.
+        rank_temp = alg_temp when the transfer positions are drawn (multinomial, :527-530) instead of ranked."""
         B, N = x.shape
         V = self.config.vocab_size
         noise_fn, trace = ctx.noise_fn, ctx.trace
@@ -407,7 +444,15 @@ class DreamGenerationMixin:
             trace.setdefault("confidence", []).append(conf.clone())
             trace.setdefault("x0", []).append(x0.clone())
         if k > 0 and M > 0:
-            st.commit(x, mask_id, M, conf, x0, k)
+            if rank_temp > 0:
+                # torch.multinomial(softmax(conf / alg_temp), k) == topk(p / q, k), q = one exponential_ fill of [B, N]
+                if ctx.rank_noise_fn is not None:
+                    q = ctx.rank_noise_fn(step, B, N).to(device=x.device, dtype=torch.float32).contiguous()
+                else:
+                    q = st.exponential_like_torch(B * N, philox_fill_plan(x.device, B * N))
+                st.commit_sampled(x, mask_id, M, conf, x0, k, rank_temp, q)
+            else:
+                st.commit(x, mask_id, M, conf, x0, k)
             st.hidden_valid = False
 
     def _step_general(self, st, x, pos, key_mask, mask_id, temperature, top_p, top_k, alg, alg_temp, t, s, last, step,

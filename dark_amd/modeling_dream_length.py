@@ -171,12 +171,14 @@ class HipState:
                                                       _hip.ptr(self.hidden), self._s()))
         self.rows_valid = False
 
-    def forward_rows(self, M: int) -> torch.Tensor:
-        """The rest of the last layer for src_rows[:M] only -> hidden_rows[:M] (dark_forward_hidden_rows)."""
-        _hip.check(self.lib.dark_forward_hidden_rows(self.pk.ref, self.B, self.N, _hip.ptr(self.src_rows), M,
+    def forward_rows(self, M: int, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The rest of the last layer for src_rows[:M] (or the given int32 row list) only -> hidden_rows[:M]
+        (dark_forward_hidden_rows)."""
+        src = self.src_rows if rows is None else rows
+        _hip.check(self.lib.dark_forward_hidden_rows(self.pk.ref, self.B, self.N, _hip.ptr(src), M,
                                                      _hip.ptr(self.fwd_ws), self.fwd_bytes, _hip.ptr(self.hidden),
                                                      _hip.ptr(self.hidden_rows), self._s()))
-        self.rows_valid = True
+        self.rows_valid = rows is None   # head_and_sample may only reuse the rows of src_rows[:M]
         return self.hidden_rows
 
     def mask_rows(self, x, mask_id) -> None:
@@ -228,6 +230,36 @@ class HipState:
                                              noise.stride(0) if noise is not None else 0, _hip.ptr(conf),
                                              _hip.ptr(x0), self._s()))
         return conf, x0
+
+    def sample_into(self, logits, n, temperature, top_p, top_k, conf_mode, noise, philox):
+        """dark_sample_rows(_philox) on `logits` [n, V] into the state's conf / x0 buffers."""
+        V = self.cfg.vocab_size
+        conf, x0 = self.conf[:n], self.x0[:n]
+        if philox is not None:
+            _hip.check(self.lib.dark_sample_rows_philox(_hip.ptr(logits), V, n, V, float(temperature), float(top_p),
+                                                        int(top_k), int(conf_mode), philox[0], philox[1], philox[2],
+                                                        _hip.ptr(conf), _hip.ptr(x0), self._s()))
+        else:
+            _hip.check(self.lib.dark_sample_rows(_hip.ptr(logits), V, n, V, float(temperature), float(top_p),
+                                                 int(top_k), int(conf_mode), _hip.ptr(noise),
+                                                 noise.stride(0) if noise is not None else 0, _hip.ptr(conf),
+                                                 _hip.ptr(x0), self._s()))
+        return conf, x0
+
+    def scatter(self, x, M, sel, tokens, n) -> None:
+        _hip.check(self.lib.dark_scatter_tokens(_hip.ptr(x), self.B, self.N, _hip.ptr(self.row_index), M,
+                                                _hip.ptr(sel.contiguous()), _hip.ptr(tokens.contiguous()), n, self._s()))
+
+    def exponential_like_torch(self, numel: int, philox) -> torch.Tensor:
+        """What `torch.empty(numel, device=...).exponential_()` would hold for the reserved Philox state."""
+        out = torch.empty(numel, dtype=torch.float32, device=self.pk.device)
+        _hip.check(self.lib.dark_philox_exponential(philox[0], philox[1], philox[2], numel, _hip.ptr(out), self._s()))
+        return out
+
+    def commit_sampled(self, x, mask_id, M, conf, x0, k, alg_temp, q) -> None:
+        _hip.check(self.lib.dark_commit_sampled(_hip.ptr(x), self.B, self.N, int(mask_id), _hip.ptr(self.row_index), M,
+                                                _hip.ptr(conf.contiguous()), _hip.ptr(x0.contiguous()), int(k),
+                                                float(alg_temp), _hip.ptr(q), self._s()))
 
     def commit(self, x, mask_id, M, conf, x0, k) -> None:
         _hip.check(self.lib.dark_commit_topk(_hip.ptr(x), self.B, self.N, int(mask_id), _hip.ptr(self.row_index),

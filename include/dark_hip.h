@@ -212,6 +212,19 @@ int dark_sample_rows_indexed(const float* logits, int64_t ldl, int n, int V, flo
 int dark_commit_topk(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M,
                      const float* conf, const int64_t* x0, int k, void* stream);
 
+/* The same commit with alg_temp > 0 (generation_utils.py:527-530): p = softmax(full_confidence / alg_temp) per row and
+ * `torch.multinomial(p, k)` without replacement, which ATen evaluates as topk(p / q, k) with q one `exponential_` fill
+ * of [B, N]: exp_noise is that fill (dark_philox_exponential reproduces torch's own stream).  A row without any masked
+ * position makes the reference raise; here its first k positions are re-masked. */
+int dark_commit_sampled(int64_t* x, int B, int N, int64_t mask_id, const int32_t* row_index, int M, const float* conf,
+                        const int64_t* x0, int k, float alg_temp, const float* exp_noise, void* stream);
+
+/* alg = 'origin' (generation_utils.py:505-510): x[mask_index] = x0 with x0 = MASK except at the masked rows that drew
+ * `rand < p_transfer`; only those n rows are sampled.  x.flat[row_index[sel[i]]] = tokens[i] for i < n
+ * (sel: int64 indices into the masked-row list, as torch.nonzero returns them). */
+int dark_scatter_tokens(int64_t* x, int B, int N, const int32_t* row_index, int M, const int64_t* sel,
+                        const int64_t* tokens, int n, void* stream);
+
 /* One whole denoise step for a batch whose masked-row count M is known on the host
  * (uniform layouts): body forward -> mask rows -> head on masked rows -> sample -> commit.
  * Replaces one iteration of the loop at generation_utils.py:488-540 for the confidence algs.

@@ -294,7 +294,9 @@ def sample_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
                 trace: Optional[SampleTrace] = None, keep_logits: bool = False,
                 forward_fn: Optional[Callable] = None, rand_fn: Optional[Callable[[int, int], torch.Tensor]] = None,
                 tie_break: str = "torch", think_sample: bool = False, think_sample_interval: int = 2,
-                sep_token_id: Optional[int] = None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                sep_token_id: Optional[int] = None,
+                rank_noise_fn: Optional[Callable[[int, int, int], torch.Tensor]] = None
+                ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """generation_utils.py:435-548.  Returns (sequences, history) with history[i] = x after step i.
 
     ``noise_fn(step, M, V)`` injects the exponential noise of the categorical draw
@@ -367,7 +369,13 @@ def sample_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
                         _, transfer_index = torch.topk(full_conf, k)
                 else:
                     full_conf = F.softmax(full_conf / alg_temp, dim=-1)
-                    transfer_index = torch.multinomial(full_conf, num_samples=k)
+                    # torch.multinomial(p, k) without replacement IS topk(p / q, k) with q = one exponential_(1) fill
+                    # of p's shape from the same generator (ATen Distributions.cpp, multinomial fast path); written
+                    # out so that the draws can be injected (`rank_noise_fn(step, B, N)`).  Checked against the
+                    # reference golden `ded_algtemp`, which the reference made with torch.multinomial itself.
+                    q = (rank_noise_fn(i, *full_conf.shape) if rank_noise_fn is not None
+                         else torch.empty_like(full_conf).exponential_(1))
+                    transfer_index = torch.topk(full_conf / q, k).indices
                 x_ = torch.zeros_like(x, dtype=torch.long) + mask_token_id
                 x_[mask_index] = x0.clone()
                 rows = torch.arange(x.size(0)).unsqueeze(1).expand_as(transfer_index)

@@ -290,6 +290,29 @@ def test_forward_rows_equals_full_forward(real, dtype):
         assert torch.equal(out, full[rows_d.long()]), (L, dtype)
 
 
+@pytest.mark.parametrize("alg,alg_temp,T", [("origin", None, 0.4), ("origin", None, 0.0), ("entropy", 0.5, 0.3),
+                                            ("maskgit_plus", 0.7, 0.5), ("topk_margin", 0.2, 0.0)])
+def test_native_variants_equal_materialised_path(real, alg, alg_temp, T):
+    """alg='origin' and alg_temp > 0 run on device kernels (dark_scatter_tokens / dark_commit_sampled, the draws taken
+    from torch's Philox stream); a no-op logits hook forces the materialised [B,N,V] path that calls torch.rand /
+    torch.multinomial itself.  Same seed: the histories and the generator's final offset must be identical."""
+    meta, _ = real
+    m = _model(dict(meta["real"], num_hidden_layers=2))
+    ids = synth.make_inputs(24, "ded", seed=12).to(DEV)
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    res = []
+    for hook in (None, (lambda step, x, logits: logits)):
+        torch.manual_seed(41)
+        kw = {} if hook is None else {"generation_logits_hook_func": hook}
+        out = m.diffusion_generate(ids, generation_config=_gc(), return_dict_in_generate=True, output_history=True,
+                                   steps=10, temperature=T, alg=alg, alg_temp=alg_temp, top_p=0.9, **kw)
+        res.append((torch.stack(out.history).cpu(), gen.get_offset()))
+    bad = (res[0][0] != res[1][0]).any(-1).any(-1).nonzero().flatten().tolist()
+    assert not bad, f"native and materialised paths differ at steps {bad}"
+    assert res[0][1] == res[1][1], "the device generator must end at the same offset"
+    assert int((res[0][0][-1] == synth.MASK).sum()) <= 2
+
+
 # --------------------------------------------------------------------------- boundary behaviour
 def test_int32_ids_are_accepted(real):
     """nn.Embedding in the reference takes int32 ids too (modeling_dream_length.py:665): the boundary casts once."""
