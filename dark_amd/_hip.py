@@ -93,6 +93,10 @@ SIGNATURES = {
     "dark_expand_commit_edit": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                           C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dark_expand_commit_edit_sampled": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                  C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                                  C.c_void_p, C.c_void_p]),
     "dark_logprob_workspace_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.c_int]),
     "dark_lm_head_logprob": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

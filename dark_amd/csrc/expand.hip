@@ -92,7 +92,8 @@ __global__ __launch_bounds__(64) void expand_commit_edit_kernel(
     int64_t* __restrict__ x, int B, int N, const int32_t* __restrict__ row_index, int M,
     const float* __restrict__ conf, const int64_t* __restrict__ x0, int k, const uint8_t* __restrict__ active,
     int32_t* __restrict__ win, int32_t* __restrict__ budget, int64_t mask_id, int64_t delete_id,
-    int64_t expand_id, int pad_delete_to_right, int64_t* __restrict__ snaps, int32_t* __restrict__ snap_len) {
+    int64_t expand_id, int pad_delete_to_right, int64_t* __restrict__ snaps, int32_t* __restrict__ snap_len,
+    float alg_temp, const float* __restrict__ qnoise) {
   __shared__ int64_t row[XN], tmp[XN + 8];
   __shared__ float cf[XN];
   __shared__ int64_t cand[XN];
@@ -126,10 +127,26 @@ __global__ __launch_bounds__(64) void expand_commit_edit_kernel(
       const int m = min(m_next + rank, M - 1);  // == m_next + rank when row_index describes this x
       cf[j] = is_mask ? conf[m] : -INFINITY;
       cand[j] = is_mask ? x0[m] : mask_id;
+      if (alg_temp > 0.f) tmp[j] = is_mask ? (int64_t)__float_as_uint(qnoise[m]) : 0;  // parked until the softmax below
     }
     m_next += __popcll(bal);
   }
   __syncthreads();
+  if (alg_temp > 0.f) {
+    // :436-439: torch.multinomial(softmax(confidence / alg_temp), k) over this sequence's masked positions ==
+    // topk(p / q, k) with q the Exp(1) draws of ATen's multinomial fast path (one fill over the masked rows)
+    float mx = -INFINITY;
+    for (int j = lane; j < N; j += 64)
+      if (was[j]) mx = fmaxf(mx, cf[j] / alg_temp);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < N; j += 64)
+      if (was[j]) sum += expf(cf[j] / alg_temp - mx);
+    sum = wave_sum(sum);
+    for (int j = lane; j < N; j += 64)
+      if (was[j]) cf[j] = (expf(cf[j] / alg_temp - mx) / sum) / __uint_as_float((uint32_t)tmp[j]);
+    __syncthreads();
+  }
   // ---- torch.topk(confidence, k) over the masked positions (ties -> lower index), :434-442
   for (int j = lane; j < N; j += 64) {
     if (!was[j]) continue;
@@ -252,6 +269,16 @@ int dark_expand_commit_edit(int64_t* x, int B, int N, const int32_t* row_index, 
                             const int64_t* x0, int k, const uint8_t* active, int32_t* win, int32_t* budget,
                             int64_t mask_id, int64_t delete_id, int64_t expand_id, int pad_delete_to_right,
                             int64_t* snaps, int32_t* snap_len, void* stream) {
+  return dark_expand_commit_edit_sampled(x, B, N, row_index, M, conf, x0, k, active, win, budget, mask_id, delete_id,
+                                         expand_id, pad_delete_to_right, snaps, snap_len, 0.f, nullptr, stream);
+}
+
+int dark_expand_commit_edit_sampled(int64_t* x, int B, int N, const int32_t* row_index, int M, const float* conf,
+                                    const int64_t* x0, int k, const uint8_t* active, int32_t* win, int32_t* budget,
+                                    int64_t mask_id, int64_t delete_id, int64_t expand_id, int pad_delete_to_right,
+                                    int64_t* snaps, int32_t* snap_len, float alg_temp, const float* exp_noise,
+                                    void* stream) {
+  DARK_CHECK_ARG(!(alg_temp > 0.f) || exp_noise || M == 0, "expand_commit_edit: alg_temp > 0 needs the [M] Exp(1) draws");
   DARK_CHECK_ARG(x && active && win && budget && (M == 0 || (row_index && conf && x0)),
                  "expand_commit_edit: null pointer");
   DARK_CHECK_ARG(B > 0 && N > 0 && N <= XN, "expand_commit_edit: N=%d must be in [1,%d]", N, XN);
@@ -259,7 +286,7 @@ int dark_expand_commit_edit(int64_t* x, int B, int N, const int32_t* row_index, 
   DARK_CHECK_ARG((snaps == nullptr) == (snap_len == nullptr), "expand_commit_edit: snaps and snap_len go together");
   hipLaunchKernelGGL(expand_commit_edit_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, B, N, row_index, M,
                      conf, x0, k, active, win, budget, mask_id, delete_id, expand_id, pad_delete_to_right, snaps,
-                     snap_len);
+                     snap_len, alg_temp, exp_noise);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }

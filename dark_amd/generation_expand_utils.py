@@ -149,6 +149,7 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
     def _generate_rows(self, rows: List[torch.Tensor], generation_config, single: bool, **kwargs):
         kwargs.pop("tokenizer", None)                                                            # :301
         noise_fn = kwargs.pop("_noise_fn", None)   # parity tests: (row, step, M_row, V) -> Exp(1) draws
+        rank_noise_fn = kwargs.pop("_rank_noise_fn", None)   # parity tests: (row, step, M_row) -> multinomial's draws
         trace = kwargs.pop("_trace", None)         # parity tests: dict receiving per-step M / conf / x0 / rows
         compact = kwargs.pop("compact_finished", True)
         lazy_noise = bool(kwargs.pop("lazy_noise", True))   # see generation_utils.diffusion_generate
@@ -193,22 +194,24 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
                 f" is on {self.device.type}. You may experience unexpected behaviors or slower generation.",
                 UserWarning)
         return self._sample(packed, prefixes, n_masks, gc, _single=single, _noise_fn=noise_fn, _trace=trace,
-                            _compact=compact, _state_hook=state_hook, _lazy_noise=lazy_noise)
+                            _compact=compact, _state_hook=state_hook, _lazy_noise=lazy_noise,
+                            _rank_noise_fn=rank_noise_fn)
 
     # ------------------------------------------------------------------ the loop
     def _sample(self, input_ids, prefix_len, start_gen_len, generation_config, _single: Optional[bool] = None,
                 _noise_fn: Optional[Callable] = None, _trace: Optional[dict] = None, _compact: bool = True,
-                _state_hook: Optional[Callable] = None, _lazy_noise: bool = True):
+                _state_hook: Optional[Callable] = None, _lazy_noise: bool = True,
+                _rank_noise_fn: Optional[Callable] = None):
         """generation_expand_utils.py:358-503 for every row at once.  `input_ids`: a `[1, L]` tensor with scalar
         `prefix_len` / `start_gen_len` (the reference signature) or lists of them."""
         if self.device.type != "cuda":
             raise RuntimeError("dark_amd runs on a HIP device only: move the model with .to('cuda')")
         with torch.cuda.device(self.device):  # the library launches on the CURRENT device's stream
             return self._sample_impl(input_ids, prefix_len, start_gen_len, generation_config, _single, _noise_fn,
-                                     _trace, _compact, _state_hook, _lazy_noise)
+                                     _trace, _compact, _state_hook, _lazy_noise, _rank_noise_fn)
 
     def _sample_impl(self, input_ids, prefix_len, start_gen_len, generation_config, _single, _noise_fn, _trace,
-                     _compact, _state_hook, _lazy_noise):
+                     _compact, _state_hook, _lazy_noise, _rank_noise_fn):
         gc = generation_config
         if isinstance(input_ids, torch.Tensor):   # the reference signature: one [1, L] prompt
             L = int(input_ids.shape[1])
@@ -239,9 +242,6 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
             raise ValueError("expand_token_id must be set in the generation config")
         stochastic_rank = not (alg_temp is None or alg_temp == 0)
         B0, V = len(lengths), self.config.vocab_size
-        if stochastic_rank and B0 > 1:
-            raise NotImplementedError("alg_temp > 0 (multinomial ranking, :436-439) is implemented for one sequence "
-                                      "per call only")
         want_history = bool(gc.return_dict_in_generate and gc.output_history)
 
         # ---- per-row state (:378-395)
@@ -289,7 +289,7 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
                 out[origin] = x
                 keep = buf.active[:B].nonzero(as_tuple=False).flatten()
                 x, win, budget, limit, origin = (t[keep].contiguous() for t in (x, win, budget, limit, origin))
-                origin_host = origin.tolist() if want_history or _noise_fn or _trace is not None else origin_host
+                origin_host = origin.tolist() if want_history or _noise_fn or _rank_noise_fn or _trace is not None else origin_host
                 B = int(keep.numel())
                 st = self._hip_state(B, N)
                 buf = _ExpandBuffers(B, N, device, want_history)
@@ -331,21 +331,28 @@ class DreamGenerationMixin(_fixed.DreamGenerationMixin):
                 _trace.setdefault("rows", []).append([origin_host[b] for b in (st.row_index[:M] // N).tolist()])
                 _trace.setdefault("confidence", []).append(conf.clone())
                 _trace.setdefault("x0", []).append(x0.clone())
+            q = None
             if stochastic_rank:
-                # :436-439 on the single sequence: multinomial over softmax(confidence / alg_temp); the chosen
-                # positions are handed to the commit as the top-k of an indicator
-                if k > M:
+                # :436-439: torch.multinomial(softmax(confidence / alg_temp), k) == topk(p / q, k) per sequence, q =
+                # the Exp(1) fill ATen's multinomial draws (one [M] fill per step: the reference's own stream when
+                # the batch is one sequence)
+                if _single and k > M:
                     raise RuntimeError(f"cannot sample {k} positions out of {M} masked ones without replacement")
-                chosen = torch.multinomial(F.softmax(conf / alg_temp, dim=-1), num_samples=k)
-                conf = torch.zeros(M, device=device, dtype=torch.float32)
-                conf[chosen] = 1.0
+                if _rank_noise_fn is not None:
+                    seq_of = (st.row_index[:M] // N).tolist()
+                    per = {}
+                    for b_live in seq_of:
+                        per[b_live] = per.get(b_live, 0) + 1
+                    q = torch.cat([_rank_noise_fn(origin_host[b_live], i, m_b).to(torch.float32).reshape(-1)
+                                   for b_live, m_b in per.items()]).to(device).contiguous()
+                else:
+                    q = st.exponential_like_torch(M, _fixed.philox_fill_plan(device, M))
             elif _single and k > M:
                 raise RuntimeError(f"selected index k out of range: topk({k}) over {M} masked positions (:435)")
-            _hip.check(lib.dark_expand_commit_edit(_hip.ptr(x), B, N, _hip.ptr(st.row_index), M, _hip.ptr(conf),
-                                                   _hip.ptr(x0), k, _hip.ptr(buf.active), _hip.ptr(win),
-                                                   _hip.ptr(budget), mask_id, delete_id, int(expand_id),
-                                                   1 if gc.pad_delete_to_right else 0, _hip.ptr(buf.snaps),
-                                                   _hip.ptr(buf.snap_len), s))
+            _hip.check(lib.dark_expand_commit_edit_sampled(
+                _hip.ptr(x), B, N, _hip.ptr(st.row_index), M, _hip.ptr(conf), _hip.ptr(x0), k, _hip.ptr(buf.active),
+                _hip.ptr(win), _hip.ptr(budget), mask_id, delete_id, int(expand_id), 1 if gc.pad_delete_to_right else 0,
+                _hip.ptr(buf.snaps), _hip.ptr(buf.snap_len), float(alg_temp) if stochastic_rank else 0.0, _hip.ptr(q), s))
             if histories is not None:
                 lens = buf.snap_len.cpu()
                 snaps = buf.snaps.clone()      # one device copy per step; the appended rows are views of it

@@ -276,6 +276,15 @@ int dark_expand_commit_edit(int64_t* x, int B, int N, const int32_t* row_index, 
                             int64_t mask_id, int64_t delete_id, int64_t expand_id, int pad_delete_to_right,
                             int64_t* snaps, int32_t* snap_len, void* stream);
 
+/* The same step with alg_temp > 0 (:436-439): the k positions of every sequence are drawn,
+ * `torch.multinomial(softmax(confidence / alg_temp), k)` == topk(p / q, k) per sequence, exp_noise [M] = the Exp(1)
+ * draws q in masked-row order (for one sequence: ATen's own fill, dark_philox_exponential reproduces it). */
+int dark_expand_commit_edit_sampled(int64_t* x, int B, int N, const int32_t* row_index, int M, const float* conf,
+                                    const int64_t* x0, int k, const uint8_t* active, int32_t* win, int32_t* budget,
+                                    int64_t mask_id, int64_t delete_id, int64_t expand_id, int pad_delete_to_right,
+                                    int64_t* snaps, int32_t* snap_len, float alg_temp, const float* exp_noise,
+                                    void* stream);
+
 /* ---- forward-only log-probabilities of the diffusion GRPO trainer, as computed under no_grad for
  * the old / reference policy in akgr/abduction_model/custom_grpo2.py:681-709.
  *

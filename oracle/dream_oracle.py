@@ -393,7 +393,9 @@ def expand_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
                 temperature: float = 0.0, top_p: Optional[float] = None, top_k: Optional[int] = None,
                 noise_fn: Optional[Callable[[int, int, int], torch.Tensor]] = None,
                 forward_fn: Optional[Callable] = None, tie_break: str = "torch",
-                trace: Optional[SampleTrace] = None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                trace: Optional[SampleTrace] = None,
+                rank_noise_fn: Optional[Callable[[int, int], torch.Tensor]] = None
+                ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """``generation_expand_utils.py:294-356`` (prefix / mask bookkeeping) + ``_sample`` ``:358-503``: the
     DreamOn-style variable-length sampler.  ``input_ids`` is ``[1, L]`` (the path inspects row 0 only, :445-495).
     Returns (x ``[1, max_length]``, history) where history holds the up to three snapshots per step the reference
@@ -453,7 +455,8 @@ def expand_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
             x, mask_index, confidence, x0, number_transfer_tokens=number_transfer_tokens, alg_temp=alg_temp,
             tie_break=tie_break, mask_token_id=mask_token_id, delete_token_id=delete_token_id,
             expand_token_id=expand_token_id, pad_delete_to_right=pad_delete_to_right, max_length=max_length,
-            window=cwl)
+            window=cwl,
+            rank_noise=(rank_noise_fn(i, confidence.numel()) if (rank_noise_fn is not None and alg_temp) else None))
         num_generation_tokens += d_gen
         expand_budget -= n_exp
         history.extend(snaps)
@@ -464,7 +467,7 @@ def expand_loop(w, cfg: OracleConfig, input_ids: torch.Tensor, *, max_length: in
 
 def expand_commit_edit(x, mask_index, confidence, x0, *, number_transfer_tokens: int, alg_temp, tie_break: str,
                        mask_token_id: int, delete_token_id: int, expand_token_id: int, pad_delete_to_right: bool,
-                       max_length: int, window: int):
+                       max_length: int, window: int, rank_noise: Optional[torch.Tensor] = None):
     """One iteration's commit and sequence edits, generation_expand_utils.py:434-495, on `x` [1, max_length].
     Returns (x, change of num_generation_tokens, number of expansions, history snapshots)."""
     snaps: List[torch.Tensor] = []
@@ -477,7 +480,11 @@ def expand_commit_edit(x, mask_index, confidence, x0, *, number_transfer_tokens:
             _, transfer_index = torch.topk(confidence, number_transfer_tokens)
     else:
         confidence = F.softmax(confidence / alg_temp, dim=-1)
-        transfer_index = torch.multinomial(confidence, num_samples=number_transfer_tokens)
+        if number_transfer_tokens > confidence.numel():
+            raise RuntimeError("cannot sample n_sample > prob_dist.size(-1) samples without replacement")
+        # torch.multinomial(p, k) without replacement == topk(p / q, k), q = one exponential_(1) fill (see sample_loop)
+        q = rank_noise if rank_noise is not None else torch.empty_like(confidence).exponential_(1)
+        transfer_index = torch.topk(confidence / q, number_transfer_tokens).indices
     x0_ = torch.zeros_like(x0, dtype=torch.long) + mask_token_id
     x0_[transfer_index] = x0[transfer_index].clone()
     x[mask_index] = x0_

@@ -194,11 +194,15 @@ NEAR_TIE = 2e-6  # as tests/test_hip_model.py: confidences are sums over V terms
 def _oracle_traced(meta, g, c):
     """The oracle on one golden case, consuming the reference's CPU RNG stream; records the noise per step."""
     kw = dict(c["kw"])
-    noise = []
+    noise, rank_noise = [], {}
 
     def nf(step, M, V):
         noise.append(torch.empty(M, V).exponential_(1))
         return noise[-1]
+
+    def rf(step, M):  # torch.multinomial's own draw (alg_temp > 0), from the same CPU stream, right after the sampler's
+        rank_noise[step] = torch.empty(M).exponential_(1)
+        return rank_noise[step]
 
     cfg = O.OracleConfig(**{k: v for k, v in meta["mini"].items() if k in O.OracleConfig.__dataclass_fields__})
     w = synth.boost_edit_tokens(synth.make_weights(cfg, seed=0, rich=True), **meta["boost"])
@@ -209,8 +213,8 @@ def _oracle_traced(meta, g, c):
                          expand_budget=kw.get("expand_budget"), pad_delete_to_right=kw.get("pad_delete_to_right", False),
                          number_transfer_tokens=kw["number_transfer_tokens"], alg=kw["alg"], alg_temp=kw["alg_temp"],
                          temperature=kw["temperature"], top_p=kw.get("top_p"), top_k=kw.get("top_k"),
-                         noise_fn=nf, tie_break="index", trace=tr)
-    return x, h, tr, noise
+                         noise_fn=nf, tie_break="index", trace=tr, rank_noise_fn=rf)
+    return x, h, tr, (noise, rank_noise)
 
 
 def test_single_sequence_matches_reference_goldens(mini, goldens_expand, golden_expand_meta):
@@ -224,11 +228,12 @@ def test_single_sequence_matches_reference_goldens(mini, goldens_expand, golden_
     cases must be bit-exact against the reference goldens end to end (the others are compared with the oracle run
     with the device's tie order, see below)."""
     exact, exact_oracle, forced_steps, tie_steps = 0, 0, 0, 0
-    cases = [c for c in golden_expand_meta["cases"] if not c["kw"].get("alg_temp")]
+    cases = list(golden_expand_meta["cases"])   # incl. alg_temp > 0: the multinomial draws are replayed too
     for c in cases:
         kw = dict(c["kw"])
         ids = torch.from_numpy(goldens_expand["in_" + c["input"]]).to(DEV)
-        xo, ho, tr, noise = _oracle_traced(golden_expand_meta, goldens_expand, c)
+        xo, ho, tr, (noise, rank_noise) = _oracle_traced(golden_expand_meta, goldens_expand, c)
+        kw["_rank_noise_fn"] = lambda row, step, M: rank_noise.get(step, torch.ones(M))
         # device top-k semantics (lowest index among EXACTLY equal confidences, e.g. entropy == 0 at several
         # positions once top-p keeps a single token) vs the CPU topk order the goldens were recorded with:
         # tests/test_oracle_expand_golden.py::test_index_tie_break_differs_only_at_ties
@@ -308,6 +313,38 @@ def test_batched_rows_equal_single_runs_and_oracle(mini, goldens_expand, golden_
             assert torch.equal(out.sequences[b].cpu(), xo[0])
             n_oracle_exact += 1
     assert n_oracle_exact >= 6, n_oracle_exact   # fp32 near-ties may part a long chain on the flat mini model
+
+
+def test_batched_alg_temp_equals_single_runs(mini, goldens_expand):
+    """alg_temp > 0 (positions DRAWN, generation_expand_utils.py:436-439) for a ragged batch: every row equals its own
+    single-sequence run on the same sampler noise and the same multinomial draws -- the restriction to one sequence
+    per call is gone.  With the device generator instead of injected draws, a batch of one consumes torch's stream
+    exactly as the reference's torch.multinomial would (same offsets as the materialised call)."""
+    names = ["abd0", "abd1", "ded0", "ded1", "withexp", "abd2"]
+    prompts = [torch.from_numpy(goldens_expand["in_" + n]) for n in names]
+    noise = _seeded_noise(9)
+
+    def rank(row, step, M):
+        return torch.empty(M).exponential_(1, generator=torch.Generator().manual_seed(1000 * row + step))
+
+    kw = dict(temperature=0.4, alg="entropy", alg_temp=0.6, top_p=0.9, number_transfer_tokens=1)
+    out = mini.diffusion_generate_batch([p.to(DEV) for p in prompts], generation_config=_gc(50),
+                                        return_dict_in_generate=True, output_history=True, _noise_fn=noise,
+                                        _rank_noise_fn=rank, **kw)
+    for b, p in enumerate(prompts):
+        single = mini.diffusion_generate(inputs=p.to(DEV), generation_config=_gc(50), return_dict_in_generate=True,
+                                         output_history=True,
+                                         _noise_fn=lambda row, step, M, V, b=b: noise(b, step, M, V),
+                                         _rank_noise_fn=lambda row, step, M, b=b: rank(b, step, M), **kw)
+        assert torch.equal(single.sequences[0], out.sequences[b]), names[b]
+        assert len(single.history) == len(out.history[b])
+    # free-running generator: k = 2 positions per step, batch of one, twice with the same seed
+    res = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        res.append(mini.diffusion_generate(inputs=prompts[0].to(DEV), generation_config=_gc(50), temperature=0.4,
+                                           alg_temp=0.6, top_p=0.9, number_transfer_tokens=2))
+    assert torch.equal(res[0], res[1])
 
 
 def test_compaction_is_invisible(mini, goldens_expand):
