@@ -44,17 +44,24 @@ PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARC
 PEAK_F32_TFLOPS = 157.3    # fp32 matrix
 
 
-def algorithmic_flops_per_call(cfg, B, N, steps, masks_per_row):
-    """F_body(N) = N*L*(8d^2 + 6*d*ff + 4*N*d) per sequence-step, F_head = 2*d*V per masked row."""
+def algorithmic_flops_per_call(cfg, B, N, steps, masks_per_row, executed=False):
+    """F_body(N) = N*L*(8d^2 + 6*d*ff + 4*N*d) per sequence-step, F_head = 2*d*V per masked row.
+    executed=True counts what this build actually runs: in the LAST layer o_proj and the MLP (2d^2 + 6*d*ff per
+    row) are evaluated for the masked rows only (dark_forward_hidden_rows) -- the other rows' outputs are read by
+    nothing in the reference either (generation_utils.py:501 drops them)."""
     from dark_amd.generation_utils import transfer_count
     d, ff, L, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.vocab_size
     body = N * L * (8 * d * d + 6 * d * ff + 4 * N * d)
+    tail_row = 2 * d * d + 6 * d * ff
     ts = torch.linspace(1, 1e-3, steps + 1)
     left, head_rows = masks_per_row, 0
     for i in range(steps):
         head_rows += left
         left -= transfer_count(left, 1, ts[i], ts[i + 1], i == steps - 1)
-    return B * (steps * body + head_rows * 2 * d * V)
+    total = steps * body + head_rows * 2 * d * V
+    if executed and L > 0:
+        total -= steps * N * tail_row - head_rows * tail_row
+    return B * total
 
 
 def main():
@@ -69,9 +76,9 @@ def main():
     ap.add_argument("--materialise-noise", action="store_true",
                     help="fill the [M,V] categorical noise with torch instead of computing it in the sampler")
     ap.add_argument("--cpu-sample", type=int, default=48, help="sequences in the CPU-oracle sample")
-    ap.add_argument("--gemm-variant", type=int, default=0, choices=[0, 1, 2],
-                    help="A/B hook: 0 = the library's choice, 1 = 128-row GEMM kernels only, 2 = persistent 256x256 "
-                         "kernel wherever it supports the shape")
+    ap.add_argument("--gemm-variant", type=int, default=0, choices=[0, 1, 2, 4],
+                    help="A/B hook: 0 = the library's choice, 1 = 128-row GEMM kernels only, 2 / 4 = the persistent 256x256 "
+                         "kernel (plain / staggered) wherever it supports the shape")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on ONE card: every rank uses cuda:0 and the collectives run over gloo (a functional "
                          "rehearsal of the multi-GPU path, not a measurement)")
@@ -141,7 +148,8 @@ def main():
         out = one_step()
     fence()
     EPI_SWIGLU = 2
-    lib.dark_prof_select_gemm(EPI_SWIGLU)
+    rows_full = half * 46  # the full-size gate/up launches (9 of 10 layers); the last layer's tail has fewer rows
+    lib.dark_prof_select_gemm_rows(EPI_SWIGLU, rows_full)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_step()
@@ -170,6 +178,8 @@ def main():
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     alg_flops = (algorithmic_flops_per_call(cfg, half, 46, args.denoise_steps, 11)
                  + algorithmic_flops_per_call(cfg, args.batch - half, 46, args.denoise_steps, 33))
+    exe_flops = (algorithmic_flops_per_call(cfg, half, 46, args.denoise_steps, 11, True)
+                 + algorithmic_flops_per_call(cfg, args.batch - half, 46, args.denoise_steps, 33, True))
     achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     result = {
         "metric": "denoised KG query sequences/sec (whole node) at T steps",
@@ -181,9 +191,13 @@ def main():
                    "batch_per_gpu": args.batch, "denoise_steps": args.denoise_steps, "temperature": 0.1,
                    "top_p": 0.9, "alg": "entropy", "parallelism": f"dp{world}", "weights": "random-init"},
         "value_skip_noop_steps": round(args.batch * world * args.steps / dt_skip, 2),
+        # SURVEY 8(d)'s algorithmic FLOPs (every row through every layer, head on masked rows) over the dense peak ...
         "forward_mfma_frac": round(alg_flops * args.steps * world / dt / 1e12 / (peak * world), 4),
+        # ... and the FLOPs this build executes (last layer's o_proj / MLP on the masked rows only)
+        "forward_mfma_frac_executed": round(exe_flops * args.steps * world / dt / 1e12 / (peak * world), 4),
         "roofline": {"bound": "mfma", "kernel": (("gemm_bf16_kernel16<2, 192>" if args.dtype == "bf16" else "gemm_f32_kernel<2>")
-                                + " = EPI_SWIGLU (gate/up projection + SiLU*up, M=B*N/2 rows per call, N=6144, K=768)"),
+                                + f" = EPI_SWIGLU (gate/up projection + SiLU*up, the {rows_full}-row launches of layers 0..L-2, "
+                                  "N=6144, K=768)"),
                      "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4),
                      # HBM-side bytes per launch from rocprofv3 PMC (FETCH_SIZE doubled per the gfx950 note, +

@@ -112,6 +112,7 @@ SIGNATURES = {
     "dark_split_strip": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dark_prof_select_gemm": (C.c_int, [C.c_int]),
+    "dark_prof_select_gemm_rows": (C.c_int, [C.c_int, C.c_int]),
     "dark_prof_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dark_dbg_gemm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                 C.c_int, C.c_int64, C.c_void_p]),

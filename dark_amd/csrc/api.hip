@@ -378,13 +378,14 @@ int dark_denoise_step(const dark_model_desc* m, int64_t* x, const int32_t* pos, 
 }
 
 int dark_prof_select_gemm(int epi) { return prof_select(epi); }
+int dark_prof_select_gemm_rows(int epi, int rows) { return prof_select(epi, rows); }
 int dark_prof_read(double* total_ms, double* total_flops, int* launches) {
   DARK_CHECK_ARG(total_ms && total_flops && launches, "prof_read: null pointer");
   return prof_read(total_ms, total_flops, launches);
 }
 
 int dark_dbg_set_gemm_variant(int variant) {
-  DARK_CHECK_ARG(variant >= 0 && variant <= 2, "set_gemm_variant: %d", variant);
+  DARK_CHECK_ARG(variant >= 0 && variant <= 4, "set_gemm_variant: %d", variant);
   set_gemm_variant(variant);
   return DARK_OK;
 }

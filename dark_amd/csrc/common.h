@@ -148,9 +148,12 @@ int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* b
 bool p256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias);
 int launch_gemm_p256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                      int64_t ldo, int w_rows, hipStream_t st);
+bool s256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias);
+int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                     int64_t ldo, int w_rows, hipStream_t st);
 void set_gemm_variant(int v);
 
-int prof_select(int epi);
+int prof_select(int epi, int rows = 0);
 int prof_read(double* total_ms, double* total_flops, int* launches);
 
 int launch_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,

@@ -524,14 +524,16 @@ static int launch_epi(int dtype, const void* A, const void* W, const float* bias
 namespace {
 struct Prof {
   int epi = -1;  // -1: off
+  int rows = 0;  // > 0: only launches with exactly this many rows
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t used = 0;
   double flops = 0.0;
 } g_prof;
 }  // namespace
 
-int prof_select(int epi) {
+int prof_select(int epi, int rows) {
   g_prof.epi = epi;
+  g_prof.rows = rows;
   g_prof.used = 0;
   g_prof.flops = 0.0;
   return DARK_OK;
@@ -558,7 +560,7 @@ static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, co
 
 int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                 int N, int K, int64_t ldo, hipStream_t st) {
-  if (g_prof.epi != epi || g_prof.used >= 8192) return launch_gemm_impl(dtype, epi, A, W, bias, out, M, N, K, ldo, st);
+  if (g_prof.epi != epi || g_prof.used >= 8192 || (g_prof.rows > 0 && g_prof.rows != M)) return launch_gemm_impl(dtype, epi, A, W, bias, out, M, N, K, ldo, st);
   if (g_prof.used == g_prof.ev.size()) {
     hipEvent_t a, b;
     DARK_CHECK_HIP(hipEventCreate(&a));
@@ -577,18 +579,29 @@ int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* b
 // 0 = automatic choice, 1 = always the 128-row kernels of this file, 2 = the persistent 256 x 256 kernel (gemm256.hip)
 // wherever it supports the shape.  Test / measurement hook (dark_dbg_set_gemm_variant).
 static std::atomic<int> g_gemm_variant{0};
-void set_gemm_variant(int v) { g_gemm_variant.store(v, std::memory_order_relaxed); }
+void set_p256_nodma(int v);
+void set_gemm_variant(int v) {  // 3 = timing probe: variant 2 with the main loop's LDS-DMA issue removed (wrong results)
+  set_p256_nodma(v == 3);
+  g_gemm_variant.store(v == 3 ? 2 : v, std::memory_order_relaxed);
+}
 
-static bool use_p256(int dtype, int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias) {
-  if (dtype != DARK_BF16) return false;
+// Which kernel serves a bf16 GEMM: 0 = the 128-row kernels of this file, 2 = gemm_bf16_p256, 4 = gemm_bf16_s256.
+// Automatic choice from the A/B of tools/gemm_ab.py (one process, interleaved rounds, M = 23552, random operands):
+//   gate/up + SwiGLU (N 6144):  128x192 196 us | p256 205 us | s256 188 us     -> s256
+//   LM head, fp32 out (N 15080): 128x128 706 us | p256 615 us | s256 611 us     -> s256
+//   q/k/v + bias (N 2304):       128x192  88 us | p256 101 us | s256  94 us     -> 128x192 (828 tiles over 256 CUs
+//                                                                                 leave the fourth round 23 % full)
+// Few rows leave the 256 CUs short of 256 x 256 tiles: those launches stay on the 128-row kernels.
+static int pick_kernel(int dtype, int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias) {
+  if (dtype != DARK_BF16) return 0;
   const int v = g_gemm_variant.load(std::memory_order_relaxed);
-  if (v == 1 || !p256_supports(epi, M, N, K, ldo, out, bias)) return false;
-  if (v == 2) return true;
-  // Automatic choice, from the A/B in tools/gemm_ab.py (one process, interleaved rounds, M = 23552): the LM head
-  // (fp32 out, N = 15080) runs 13 % faster on the 256-wide persistent kernel (606 vs 698 us); gate/up ties (202.5 vs
-  // 203.4 us: its SwiGLU epilogue is exposed at one workgroup per CU) and q/k/v loses to tile quantisation (828
-  // tiles over 256 CUs).  Small row counts leave the 256 CUs short of tiles.
-  return epi == EPI_F32 && (int64_t)cdiv(M, 256) * cdiv(N, 256) >= 512;
+  if (v == 1) return 0;
+  const bool p_ok = p256_supports(epi, M, N, K, ldo, out, bias), s_ok = s256_supports(epi, M, N, K, ldo, out, bias);
+  if (v == 2) return p_ok ? 2 : 0;
+  if (v == 4) return s_ok ? 4 : 0;
+  const bool enough_tiles = (int64_t)cdiv(M, 256) * cdiv(N, 256) >= 512;
+  if (s_ok && enough_tiles && (epi == EPI_F32 || epi == EPI_SWIGLU)) return 4;
+  return 0;
 }
 
 static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
@@ -598,9 +611,11 @@ static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, co
   DARK_CHECK_ARG(K % 64 == 0, "gemm: K=%d must be a multiple of 64", K);
   DARK_CHECK_ARG(M < (1 << 24) && N < (1 << 24), "gemm: M=%d N=%d too large", M, N);
   DARK_CHECK_ARG(A && W && out, "gemm: null operand");
-  if (use_p256(dtype, epi, M, N, K, ldo, out, bias)) {
+  const int kern = pick_kernel(dtype, epi, M, N, K, ldo, out, bias);
+  if (kern != 0) {
     DARK_CHECK_ARG(epi != EPI_BIAS || bias != nullptr, "gemm: EPI_BIAS needs a bias");
-    return launch_gemm_p256(epi, A, W, bias, out, M, N, K, ldo, cdiv(N, 128) * 128, st);
+    return kern == 4 ? launch_gemm_s256(epi, A, W, bias, out, M, N, K, ldo, cdiv(N, 128) * 128, st)
+                     : launch_gemm_p256(epi, A, W, bias, out, M, N, K, ldo, cdiv(N, 128) * 128, st);
   }
   switch (epi) {
     case EPI_BIAS:

@@ -18,7 +18,8 @@
 //     from an empty pipeline.
 // Staging: buffer_load_dwordx4 ... lds (LDS-DMA, 1 KiB per wave-instruction); the LDS image is lane-linear with the
 // XOR swizzle of gemm.hip applied to the per-lane SOURCE offset.  Out-of-range rows are read as zeros by the buffer
-// descriptor's bounds check, so edge tiles need no clamping.
+// descriptor's bounds check (row offsets travel in the VGPR operand, the only one the check covers), so edge tiles
+// need no clamping.
 #include "common.h"
 
 namespace dark {
@@ -58,7 +59,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 }  // namespace
 
-template <int EPI>
+template <int EPI, bool NODMA = false>
 __global__ __launch_bounds__(512) void gemm_bf16_p256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ bias, void* __restrict__ out, int M,
                                                       int N, int K, int64_t ldo, int tilesM, int tilesN, int ntiles,
@@ -91,13 +92,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256(const bf16_t* __restrict__
     for (int q = 0; q < 4; ++q) {
       const int p = wave * 4 + q;  // piece 0..31 of the operand tile
       const unsigned so = (unsigned)p * 8u * kb + (unsigned)kt * (PBK * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + p * 1024), 16, voff[q & 1], a0 + so, 0, 0);
+      // (the whole offset goes into the VGPR operand: the SGPR offset is EXCLUDED from the descriptor's bounds check)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + p * 1024), 16, voff[q & 1] + (a0 + so), 0, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int p = wave * 4 + q;
       const unsigned so = (unsigned)p * 8u * kb + (unsigned)kt * (PBK * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + P_OPER + p * 1024), 16, voff[q & 1], w0 + so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + P_OPER + p * 1024), 16, voff[q & 1] + (w0 + so), 0, 0, 0);
     }
   };
 
@@ -190,8 +192,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256(const bf16_t* __restrict__
       __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (kt + 2 < KT) stage(buf, a0, w0, kt + 2);
-      else if (nid < ntiles) stage(buf, na0, nw0, (kt + 2 - KT) % KT);  // the next output tile's K-tiles 0 and 1
+      if constexpr (!NODMA) {  // (NODMA: timing probe only -- what the main loop costs without its LDS-DMA issue)
+        if (kt + 2 < KT) stage(buf, a0, w0, kt + 2);
+        else if (nid < ntiles) stage(buf, na0, nw0, (kt + 2 - KT) % KT);  // the next output tile's K-tiles 0 and 1
+      }
       if (kt + 1 < KT) rd(fa0, fw0, buf ^ 1, ch0);
       __builtin_amdgcn_sched_barrier(0);
       mm(fa1, fw1);
@@ -240,6 +244,230 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256(const bf16_t* __restrict__
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ====================================================================================================================
+// Staggered variant (s256): what the measurements on gemm_bf16_p256 asked for.  Timing that kernel with its main-loop
+// LDS-DMA issue removed (dark_dbg_set_gemm_variant(3)) takes the K-tile from 1.51 to 1.20 us: a wave spends ~80 cycles
+// issuing each `buffer_load ... lds`, all eight waves do it at the same point behind the barrier, and no wave feeds the
+// MFMA pipe meanwhile; the SwiGLU epilogue (exp2 + rcp per output) is exposed in the same way, 4 us per output tile.
+// Here the eight waves are two groups of four (wave >= 4 is the partner of wave - 4 on its SIMD) that run the SAME
+// program one barrier interval apart: while one group's 32 MFMAs of a K-tile execute, the other group reads its
+// fragments for the next K-tile and issues its share of the LDS-DMA (and, at a tile boundary, runs its epilogue), then
+// the roles swap.  K-tiles are 32 deep (one MFMA phase per wave and K-tile), four of them live in LDS (4 x 32 KiB), the
+// DMA runs three K-tiles ahead and continues across output tiles; one fragment set in registers suffices.
+//   LDS image of an operand K-tile: 256 rows x 64 B, lane-linear in 16-row pieces (one wave-instruction each); the
+//   16-B chunk c of row r sits at position c ^ ((r >> 2) & 2), which makes the ds_read_b128 fragment reads
+//   conflict-free (searched exhaustively over the four 16-lane groups); applied to the per-lane SOURCE offset.
+// Output goes through buffer stores: rows >= M and columns >= N fall outside the descriptor and are dropped by the
+// hardware, so every wave issues the same number of stores per tile and the counted `vmcnt` waits stay exact.
+namespace {
+constexpr int SBK = 32, S_NBUF = 4;
+constexpr int S_OPER = 256 * SBK * 2;   // 16 KiB per operand K-tile
+constexpr int S_BUF = 2 * S_OPER;       // 32 KiB per K-tile
+constexpr int S_SMEM = S_NBUF * S_BUF;  // 128 KiB
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int EPI> struct StoresPerTile;                                   // buffer stores a wave issues per tile
+template <> struct StoresPerTile<EPI_SWIGLU> { static constexpr int N = 8; };
+template <> struct StoresPerTile<EPI_BIAS> { static constexpr int N = 16; };
+template <> struct StoresPerTile<EPI_F32> { static constexpr int N = 32; };
+constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }  // vmcnt(n), nothing else
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                      const float* __restrict__ bias, void* __restrict__ out, int M,
+                                                      int N, int K, int64_t ldo, int tilesM, int tilesN, int ntiles,
+                                                      unsigned a_bytes, unsigned w_bytes, unsigned o_bytes) {
+  constexpr int GM = 8;
+  constexpr int NST = StoresPerTile<EPI>::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;  // group = row half of the tile
+  const int G = gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, G);
+  if (wg >= ntiles) return;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)o_bytes, 0x00020000);
+  const unsigned kb = (unsigned)K * 2u;
+  // piece = 16 rows x 64 B: lane l -> row (l >> 2), position l & 3 holds logical chunk (l & 3) ^ ((l >> 4) & 2)
+  const unsigned voff = (unsigned)(lane >> 2) * kb + (unsigned)(((lane & 3) ^ ((lane >> 4) & 2)) << 4);
+  auto stage = [&](int buf, unsigned a0, unsigned w0, int kt) {  // this wave's 2 + 2 pieces of K-tile kt
+    char* base = smem + buf * S_BUF;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = wave * 2 + q;
+      const unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
+      // (the whole offset goes into the VGPR operand: the SGPR offset is EXCLUDED from the descriptor's bounds check)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + p * 1024), 16, voff + (a0 + so), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + S_OPER + p * 1024), 16, voff + (w0 + so), 0, 0, 0);
+    }
+  };
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int fch = (fq ^ ((frow >> 2) & 2)) << 4;
+  const int a_rd = (grp * 128 + frow) * 64 + fch, w_rd = S_OPER + (wn * 64 + frow) * 64 + fch;
+
+  auto tile_of = [&](int id, int& tm, int& tn) {
+    const int per_group = GM * tilesN;
+    const int group = id / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(GM, tilesM - first_m);
+    const int rem = id - group * per_group;
+    tn = rem / gsz;
+    tm = first_m + (rem - tn * gsz);
+  };
+
+  const int KT = K / SBK;  // >= 4
+  // ---- DMA cursor: the K-tile that is staged next (three phases ahead of the one being read)
+  int d_id = wg, d_kt = 0, d_buf = 0;
+  unsigned d_a0, d_w0;
+  {
+    int tm, tn;
+    tile_of(d_id, tm, tn);
+    d_a0 = (unsigned)tm * 256u * kb;
+    d_w0 = (unsigned)tn * 256u * kb;
+  }
+  auto stage_next = [&]() {
+    if (d_id < ntiles) stage(d_buf, d_a0, d_w0, d_kt);
+    else {  // past the last tile: keep the per-phase DMA count constant (the counted waits rely on it)
+      stage(d_buf, 0xF0000000u, 0xF0000000u, 0);  // out of range: nothing is fetched, zeros land in a dead buffer
+    }
+    d_buf = (d_buf + 1) & (S_NBUF - 1);
+    if (++d_kt == KT) {
+      d_kt = 0;
+      d_id += G;
+      if (d_id < ntiles) {
+        int tm, tn;
+        tile_of(d_id, tm, tn);
+        d_a0 = (unsigned)tm * 256u * kb;
+        d_w0 = (unsigned)tn * 256u * kb;
+      }
+    }
+  };
+  stage_next();
+  stage_next();
+  stage_next();
+  __builtin_amdgcn_s_waitcnt(waitcnt_vm(8));  // K-tile 0 has landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one interval behind group 0
+
+  f32x4 acc[P_NI][P_MI];
+  bf16x8 fa[P_MI], fw[P_NI];
+  int rbuf = 0;  // LDS buffer of the K-tile being read
+
+  // epilogue of the tile at (m0, n0): this lane owns row (lane & 15) of each 16-row tile, 4 consecutive columns of
+  // each 16-column tile; exactly NST buffer stores per wave (out-of-range ones are dropped by the descriptor)
+  auto epilogue = [&](int m0, int n0) {
+#pragma unroll
+    for (int mi = 0; mi < P_MI; ++mi) {
+      const int m = m0 + grp * 128 + mi * 16 + frow;
+      if constexpr (EPI == EPI_SWIGLU) {
+        float v[2][4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[p][e] = silu_hw(acc[2 * p][mi][e]) * acc[2 * p + 1][mi][e];
+        const uint32_t a_lo = pk_bf16(v[0][0], v[0][1]), a_hi = pk_bf16(v[0][2], v[0][3]);
+        const uint32_t b_lo = pk_bf16(v[1][0], v[1][1]), b_hi = pk_bf16(v[1][2], v[1][3]);
+        const auto sx = __builtin_amdgcn_permlane16_swap(a_lo, b_lo, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(a_hi, b_hi, false, false);
+        const int c = ((n0 + wn * 64) >> 1) + ((fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq);
+        const unsigned off = (m < M && c + 8 <= (N >> 1)) ? (unsigned)(((int64_t)m * ldo + c) * 2) : 0xF0000000u;
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){sx[0], sy[0], sx[1], sy[1]}, ro, off, 0, 0);
+      } else if constexpr (EPI == EPI_BIAS) {
+        const float* bl = (const float*)(smem + S_SMEM);  // the whole bias vector, copied to LDS at kernel start
+#pragma unroll
+        for (int np = 0; np < 2; ++np) {
+          float v[2][4];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int ni = 2 * np + t;
+            const float4 b4 = *(const float4*)(bl + n0 + wn * 64 + ni * 16 + 4 * fq);
+            v[t][0] = acc[ni][mi][0] + b4.x; v[t][1] = acc[ni][mi][1] + b4.y;
+            v[t][2] = acc[ni][mi][2] + b4.z; v[t][3] = acc[ni][mi][3] + b4.w;
+          }
+          const uint32_t a_lo = pk_bf16(v[0][0], v[0][1]), a_hi = pk_bf16(v[0][2], v[0][3]);
+          const uint32_t b_lo = pk_bf16(v[1][0], v[1][1]), b_hi = pk_bf16(v[1][2], v[1][3]);
+          const auto sx = __builtin_amdgcn_permlane16_swap(a_lo, b_lo, false, false);
+          const auto sy = __builtin_amdgcn_permlane16_swap(a_hi, b_hi, false, false);
+          const int c = n0 + wn * 64 + np * 32 + ((fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq);
+          const unsigned off = (m < M && c + 8 <= N) ? (unsigned)(((int64_t)m * ldo + c) * 2) : 0xF0000000u;
+          __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){sx[0], sy[0], sx[1], sy[1]}, ro, off, 0, 0);
+        }
+      } else {  // EPI_F32
+#pragma unroll
+        for (int ni = 0; ni < P_NI; ++ni) {
+          const int c = n0 + wn * 64 + ni * 16 + 4 * fq;
+          const unsigned off = (m < M && c + 4 <= N) ? (unsigned)(((int64_t)m * ldo + c) * 4) : 0xF0000000u;
+          const f32x4 a = acc[ni][mi];
+          __builtin_amdgcn_raw_buffer_store_b128(
+              (u32x4_t){__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])}, ro,
+              off, 0, 0);
+        }
+      }
+    }
+  };
+
+  if constexpr (EPI == EPI_BIAS) {  // bias -> LDS behind the K-tile buffers (ordinary loads: before the steady state)
+    float* bl = (float*)(smem + S_SMEM);
+    const int npad = tilesN * 256;
+    for (int i = tid; i < npad; i += 512) bl[i] = i < N ? bias[i] : 0.f;
+    // (visible to every wave behind the first barrier of the loop below)
+  }
+
+  int pm0 = 0, pn0 = 0;   // the tile whose accumulators are waiting for their epilogue
+  bool pending = false;
+  for (int id = wg; id < ntiles; id += G) {
+    int tm, tn;
+    tile_of(id, tm, tn);
+    for (int kt = 0; kt < KT; ++kt) {
+      // ================= LOAD interval =================
+      if (kt == 0 && pending) epilogue(pm0, pn0);   // the partner group's MFMAs run meanwhile
+      {
+        const char* as = smem + rbuf * S_BUF + a_rd;
+        const char* ws = smem + rbuf * S_BUF + w_rd;
+#pragma unroll
+        for (int j = 0; j < P_NI; ++j) fw[j] = *(const bf16x8*)(ws + j * 1024);
+#pragma unroll
+        for (int i = 0; i < P_MI; ++i) fa[i] = *(const bf16x8*)(as + i * 1024);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      stage_next();  // K-tile three phases ahead, into the buffer both groups finished reading one interval ago
+      __builtin_amdgcn_sched_barrier(0);
+      // this wave's pieces of the NEXT K-tile have landed: its batch is followed by two younger batches (8 DMAs)
+      // and, for the two phases behind an epilogue, by that epilogue's NST stores
+      if (pending && kt < 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(8 + NST) & 0xF0FF);  // + lgkmcnt(0)
+      else __builtin_amdgcn_s_waitcnt(waitcnt_vm(8) & 0xF0FF);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ================= MFMA interval =================
+      if (kt == 0) {
+#pragma unroll
+        for (int j = 0; j < P_NI; ++j)
+#pragma unroll
+          for (int i = 0; i < P_MI; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < P_NI; ++j)
+#pragma unroll
+          for (int i = 0; i < P_MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      rbuf = (rbuf + 1) & (S_NBUF - 1);
+    }
+    pm0 = tm * 256;
+    pn0 = tn * 256;
+    pending = true;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's last interval
+  epilogue(pm0, pn0);
+  __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+}
+
 // Can this shape go to the persistent 256-wide kernel?  (16-byte output pieces, K tiles of 64, 32-bit buffer sizes.)
 bool p256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias) {
   if (epi != EPI_SWIGLU && epi != EPI_BIAS && epi != EPI_F32) return false;
@@ -251,6 +479,9 @@ bool p256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, c
   if ((int64_t)M * K * 2 >= (1ll << 31) || ((int64_t)N + 256) * K * 2 >= (1ll << 31)) return false;
   return true;
 }
+
+static std::atomic<int> g_p256_nodma{0};
+void set_p256_nodma(int v) { g_p256_nodma.store(v); }
 
 int launch_gemm_p256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                      int64_t ldo, int w_rows, hipStream_t st) {
@@ -276,10 +507,51 @@ int launch_gemm_p256(int epi, const void* A, const void* W, const float* bias, v
     hipLaunchKernelGGL((gemm_bf16_p256<E>), dim3(grid), dim3(512), P_SMEM, st, (const bf16_t*)A, (const bf16_t*)W, \
                        bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes);                         \
   }
-  if (epi == EPI_SWIGLU) DARK_P256(EPI_SWIGLU)
+  if (epi == EPI_SWIGLU && g_p256_nodma.load()) {
+    static SmemOptIn optin;
+    DARK_TRY(optin.ensure((const void*)gemm_bf16_p256<EPI_SWIGLU, true>, P_SMEM, st));
+    hipLaunchKernelGGL((gemm_bf16_p256<EPI_SWIGLU, true>), dim3(grid), dim3(512), P_SMEM, st, (const bf16_t*)A,
+                       (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes);
+  } else if (epi == EPI_SWIGLU) DARK_P256(EPI_SWIGLU)
   else if (epi == EPI_BIAS) DARK_P256(EPI_BIAS)
   else DARK_P256(EPI_F32)
 #undef DARK_P256
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+bool s256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias) {
+  if (!p256_supports(epi, M, N, K, ldo, out, bias) || K < 128) return false;
+  const int64_t es = epi == EPI_F32 ? 4 : 2;
+  if (((int64_t)M + 256) * ldo * es >= 0xE0000000ll) return false;  // 32-bit byte offsets of the buffer stores
+  if (epi == EPI_BIAS && (cdiv(N, 256) * 256 * 4 > 160 * 1024 - S_SMEM || ((uintptr_t)bias & 3))) return false;
+  return true;
+}
+
+int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                     int64_t ldo, int w_rows, hipStream_t st) {
+  DARK_CHECK_ARG(s256_supports(epi, M, N, K, ldo, out, bias), "gemm_s256: unsupported shape M=%d N=%d K=%d", M, N, K);
+  const int tilesM = cdiv(M, 256), tilesN = cdiv(N, 256);
+  const int ntiles = tilesM * tilesN;
+  int dev = 0, cus = 0;
+  DARK_CHECK_HIP(hipGetDevice(&dev));
+  DARK_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int grid = min(ntiles, cus);
+  const int64_t es = epi == EPI_F32 ? 4 : 2;
+  const unsigned a_bytes = (unsigned)((int64_t)M * K * 2), w_bytes = (unsigned)((int64_t)w_rows * K * 2);
+  const unsigned o_bytes = (unsigned)((int64_t)M * ldo * es);
+  const int smem = S_SMEM + (epi == EPI_BIAS ? tilesN * 256 * 4 : 0);
+#define DARK_S256(E)                                                                                               \
+  {                                                                                                                \
+    static SmemOptIn optin;                                                                                        \
+    DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<E>, smem, st));                                              \
+    hipLaunchKernelGGL((gemm_bf16_s256<E>), dim3(grid), dim3(512), smem, st, (const bf16_t*)A, (const bf16_t*)W,   \
+                       bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes);                \
+  }
+  if (epi == EPI_SWIGLU) DARK_S256(EPI_SWIGLU)
+  else if (epi == EPI_BIAS) DARK_S256(EPI_BIAS)
+  else DARK_S256(EPI_F32)
+#undef DARK_S256
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }

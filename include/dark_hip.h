@@ -333,6 +333,9 @@ int dark_split_strip(const int64_t* ids, int B, int N, int64_t sep_id, uint64_t 
  * and their number, and resets the counters.  Used by bench.py for the live roofline figure; event
  * objects are created on first use while the hook is on (the only allocation in the library). */
 int dark_prof_select_gemm(int epi);
+/* the same, restricted to launches with exactly `rows` rows of A (0 = any): the last layer's tail runs the same
+ * flavour on fewer rows (dark_forward_hidden_rows), the roofline figure is quoted on the full-size launches */
+int dark_prof_select_gemm_rows(int epi, int rows);
 int dark_prof_read(double* total_ms, double* total_flops, int* launches);
 
 /* ---- unit-test hooks (no counterpart in the reference): launch ONE kernel of the path so that
@@ -344,7 +347,8 @@ int dark_prof_read(double* total_ms, double* total_flops, int* launches);
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                   int N, int K, int64_t ldo, void* stream);
 /* Which bf16 GEMM kernel dark_dbg_gemm and the forward use: 0 = the library's choice per shape, 1 = always the
- * 128-row kernels, 2 = the persistent 256 x 256 kernel wherever it supports the shape (A/B measurements, tests). */
+ * 128-row kernels, 2 = the persistent 256 x 256 kernel wherever it supports the shape, 4 = its staggered two-group
+ * form, 3 = timing probe (variant 2 without its main-loop LDS-DMA: wrong results).  A/B measurements and tests. */
 int dark_dbg_set_gemm_variant(int variant);
 int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                        const uint8_t* key_mask, void* out, int B, int N, int H, int HD, int max_pos,
