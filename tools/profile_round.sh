@@ -25,7 +25,7 @@ grep -h '^{' "$OUT/trace.log" | tail -1 > "$OUT/${TAG}_bench_under_trace.json"
     CMD=$BENCH1 run $name --pmc $pass || exit 1
     DBP=$(find "$OUT/$name" -name "*.db" | head -1)
     echo "# ---- pass $pass"
-    python3 $R/tools/pmc_query.py "$DBP" --min-grid 100000
+    python3 $R/tools/pmc_query.py "$DBP" --min-grid 100000 --full-size
   done
 } > "$OUT/${TAG}_pmc.txt" 2> "$OUT/pmc.err"
 tail -3 "$OUT/pmc.err"
