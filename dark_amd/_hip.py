@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdark_hip.so")
 
-DARK_OK = 0
+DARK_OK, DARK_ERR_ARG, DARK_ERR_HIP, DARK_ERR_UNSUPPORTED = 0, 1, 2, 3
 DARK_F32, DARK_BF16 = 0, 1
 CONF_PROB, CONF_MARGIN, CONF_NEG_ENTROPY = 0, 1, 2
 ABI_VERSION = 3
@@ -119,6 +119,8 @@ SIGNATURES = {
     "dark_dbg_set_gemm_variant": (C.c_int, [C.c_int]),
     "dark_dbg_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dark_dbg_gemm_resid_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_float, C.c_void_p]),
     "dark_dbg_rmsnorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_int, C.c_float, C.c_void_p]),
     "dark_dbg_embed": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

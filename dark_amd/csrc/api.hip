@@ -50,6 +50,23 @@ static FwdWs carve_fwd(const dark_model_desc* m, size_t rows, char* base) {
   return w;
 }
 
+// hidden += A * W^T (o_proj / down_proj), then -- when `ln` is given -- xn = RMSNorm(hidden) * ln for the next
+// projection: the residual GEMM and the norm as two launches.  Variant 5 (dark_dbg_set_gemm_variant) routes bf16
+// models of width 768 through the row-panel kernel that does both from one set of registers (gemm_rowpanel.hip);
+// it is NOT the default: measured in the denoise loop it is 6 % slower end to end (2675 vs 2835 sequences/s,
+// profiles/r02q_rowpanel_ab.txt) -- its 246 workgroups run in lockstep, so the 180 MB residual read-modify-write of all
+// epilogues hits HBM at once with no MFMA work left to hide it, where the multi-round 128 x 192 kernel overlaps
+// one tile's epilogue with its neighbours' main loops.
+static int resid_gemm_norm(const dark_model_desc* m, const void* A, const void* W, float* hidden, const float* ln,
+                           void* xn, int M, int K, hipStream_t st) {
+  const int d = m->d;
+  if (m->dtype == DARK_BF16 && gemm_variant() == 5 && rowpanel_supports(M, d, K, A, W, hidden, ln, ln ? xn : nullptr))
+    return launch_gemm_resid_norm(A, W, hidden, ln, ln ? xn : nullptr, M, K, m->rms_eps, st);
+  DARK_TRY(launch_gemm(m->dtype, EPI_RESID, A, W, nullptr, hidden, M, d, K, d, st));
+  if (ln) DARK_TRY(launch_rmsnorm(m->dtype, hidden, ln, xn, nullptr, M, M, d, m->rms_eps, st));
+  return DARK_OK;
+}
+
 // `tail_rows` = false: the whole body.  true: stop after the LAST layer's attention -- what is left of that layer
 // (o_proj, residual, norm, MLP, residual) only matters for the rows the head will read and is done by forward_tail.
 static int forward_hidden(const dark_model_desc* m, const int64_t* ids, const int32_t* pos,
@@ -73,15 +90,16 @@ static int forward_hidden(const dark_model_desc* m, const int64_t* ids, const in
   for (int l = 0; l < m->n_layers; ++l) {
     const dark_layer_weights& L = m->layers[l];
     DARK_CHECK_ARG(L.w_qkv && L.b_qkv && L.w_o && L.w_gu && L.w_down && L.ln1 && L.ln2, "layer %d: null weight", l);
-    if (l > 0) DARK_TRY(launch_rmsnorm(m->dtype, hidden, L.ln1, w.xn, nullptr, M, M, d, m->rms_eps, st));
+    // (w.xn = this layer's normalised input: from embed_norm for layer 0, from the previous down_proj's epilogue after)
     DARK_TRY(launch_gemm(m->dtype, EPI_BIAS, w.xn, L.w_qkv, L.b_qkv, w.qkv, M, 3 * d, d, 3 * d, st));
     DARK_TRY(launch_attention(m->dtype, w.qkv, m->rope_cos, m->rope_sin, pos, key_mask, w.att, B, N, m->n_heads,
                               m->head_dim, m->max_pos, st));
     if (tail_rows && l == m->n_layers - 1) break;
-    DARK_TRY(launch_gemm(m->dtype, EPI_RESID, w.att, L.w_o, nullptr, hidden, M, d, d, d, st));
-    DARK_TRY(launch_rmsnorm(m->dtype, hidden, L.ln2, w.xn, nullptr, M, M, d, m->rms_eps, st));
+    DARK_TRY(resid_gemm_norm(m, w.att, L.w_o, hidden, L.ln2, w.xn, M, d, st));
     DARK_TRY(launch_gemm(m->dtype, EPI_SWIGLU, w.xn, L.w_gu, nullptr, w.act, M, 2 * m->ff, d, m->ff, st));
-    DARK_TRY(launch_gemm(m->dtype, EPI_RESID, w.act, L.w_down, nullptr, hidden, M, d, m->ff, d, st));
+    const float* ln_next = l + 1 < m->n_layers ? m->layers[l + 1].ln1 : nullptr;  // the final norm runs on gathered rows
+    DARK_CHECK_ARG(l + 1 >= m->n_layers || ln_next, "layer %d: null weight", l + 1);
+    DARK_TRY(resid_gemm_norm(m, w.act, L.w_down, hidden, ln_next, w.xn, M, m->ff, st));
   }
   return DARK_OK;
 }
@@ -103,10 +121,9 @@ static int forward_tail(const dark_model_desc* m, int B, int N, const int32_t* r
   const dark_layer_weights& L = m->layers[m->n_layers - 1];
   char *att_c = w.xn, *xn_c = w.qkv;
   DARK_TRY(launch_gather_rows(m->dtype, w.att, att_c, hidden, hidden_rows, rows, n_src, R, d, st));
-  DARK_TRY(launch_gemm(m->dtype, EPI_RESID, att_c, L.w_o, nullptr, hidden_rows, R, d, d, d, st));
-  DARK_TRY(launch_rmsnorm(m->dtype, hidden_rows, L.ln2, xn_c, nullptr, R, R, d, m->rms_eps, st));
+  DARK_TRY(resid_gemm_norm(m, att_c, L.w_o, hidden_rows, L.ln2, xn_c, R, d, st));
   DARK_TRY(launch_gemm(m->dtype, EPI_SWIGLU, xn_c, L.w_gu, nullptr, w.act, R, 2 * m->ff, d, m->ff, st));
-  DARK_TRY(launch_gemm(m->dtype, EPI_RESID, w.act, L.w_down, nullptr, hidden_rows, R, d, m->ff, d, st));
+  DARK_TRY(resid_gemm_norm(m, w.act, L.w_down, hidden_rows, nullptr, nullptr, R, m->ff, st));
   return DARK_OK;
 }
 
@@ -385,7 +402,7 @@ int dark_prof_read(double* total_ms, double* total_flops, int* launches) {
 }
 
 int dark_dbg_set_gemm_variant(int variant) {
-  DARK_CHECK_ARG(variant >= 0 && variant <= 4, "set_gemm_variant: %d", variant);
+  DARK_CHECK_ARG(variant >= 0 && variant <= 5, "set_gemm_variant: %d", variant);
   set_gemm_variant(variant);
   return DARK_OK;
 }
@@ -394,6 +411,10 @@ int dark_dbg_set_gemm_variant(int variant) {
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                   int64_t ldo, void* stream) {
   return launch_gemm(dtype, epi, A, W, bias, out, M, N, K, ldo, (hipStream_t)stream);
+}
+int dark_dbg_gemm_resid_norm(const void* A, const void* W, float* hidden, const float* ln_w, void* xn, int M, int K,
+                             float eps, void* stream) {
+  return launch_gemm_resid_norm(A, W, hidden, ln_w, xn, M, K, eps, (hipStream_t)stream);
 }
 int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                        const uint8_t* key_mask, void* out, int B, int N, int H, int HD, int max_pos, void* stream) {

@@ -152,6 +152,13 @@ bool s256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, c
 int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                      int64_t ldo, int w_rows, hipStream_t st);
 void set_gemm_variant(int v);
+int gemm_variant();
+// gemm_rowpanel.hip: hidden[M,768] += A[M,K] W[768,K]^T (fp32 residual, in place) and, with ln_w / xn non-null,
+// xn = bf16(ln_w * hidden / rms(hidden)) from the same registers (bf16 operands, N = 768 only)
+bool rowpanel_supports(int M, int N, int K, const void* A, const void* W, const void* hidden, const void* ln_w,
+                       const void* xn);
+int launch_gemm_resid_norm(const void* A, const void* W, float* hidden, const float* ln_w, void* xn, int M, int K,
+                           float eps, hipStream_t st);
 
 int prof_select(int epi, int rows = 0);
 int prof_read(double* total_ms, double* total_flops, int* launches);

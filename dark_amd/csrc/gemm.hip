@@ -579,6 +579,7 @@ int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* b
 // 0 = automatic choice, 1 = always the 128-row kernels of this file, 2 = the persistent 256 x 256 kernel (gemm256.hip)
 // wherever it supports the shape.  Test / measurement hook (dark_dbg_set_gemm_variant).
 static std::atomic<int> g_gemm_variant{0};
+int gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 void set_p256_nodma(int v);
 void set_gemm_variant(int v) {  // 3 = timing probe: variant 2 with the main loop's LDS-DMA issue removed (wrong results)
   set_p256_nodma(v == 3);
@@ -594,7 +595,8 @@ void set_gemm_variant(int v) {  // 3 = timing probe: variant 2 with the main loo
 // Few rows leave the 256 CUs short of 256 x 256 tiles: those launches stay on the 128-row kernels.
 static int pick_kernel(int dtype, int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias) {
   if (dtype != DARK_BF16) return 0;
-  const int v = g_gemm_variant.load(std::memory_order_relaxed);
+  int v = g_gemm_variant.load(std::memory_order_relaxed);
+  if (v == 5) v = 0;  // 5 = automatic GEMM choice + the row-panel kernel for o_proj / down_proj (api.hip)
   if (v == 1) return 0;
   const bool p_ok = p256_supports(epi, M, N, K, ldo, out, bias), s_ok = s256_supports(epi, M, N, K, ldo, out, bias);
   if (v == 2) return p_ok ? 2 : 0;

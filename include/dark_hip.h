@@ -346,9 +346,17 @@ int dark_prof_read(double* total_ms, double* total_flops, int* launches);
  *        float [M] target logits.  W has rows padded to 128. */
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                   int N, int K, int64_t ldo, void* stream);
+/* The row-panel kernel that variant 5 of dark_dbg_set_gemm_variant puts behind the forward's o_proj / down_proj for
+ * bf16 models of width 768 (gemm_rowpanel.hip; not the default):
+ * hidden[M,768] (fp32, in place) += A[M,K] * W[768,K]^T and, when ln_w and xn are given (both or neither),
+ * xn[M,768] (bf16) = ln_w * hidden / sqrt(mean(hidden^2) + eps) from the same registers.  K a multiple of 96,
+ * 16-byte aligned pointers; anything else is refused (DARK_ERR_ARG).  Replaces nn.Linear + residual add +
+ * DreamRMSNorm of modeling_dream_length.py:384/:451/:69-74 (attention) and :222/:458 (MLP). */
+int dark_dbg_gemm_resid_norm(const void* A, const void* W, float* hidden, const float* ln_w, void* xn, int M, int K,
+                             float eps, void* stream);
 /* Which bf16 GEMM kernel dark_dbg_gemm and the forward use: 0 = the library's choice per shape, 1 = always the
- * 128-row kernels, 2 = the persistent 256 x 256 kernel wherever it supports the shape, 4 = its staggered two-group
- * form, 3 = timing probe (variant 2 without its main-loop LDS-DMA: wrong results).  A/B measurements and tests. */
+ * 128-row kernels (and the residual GEMM + norm as two launches), 2 = the persistent 256 x 256 kernel wherever it supports the shape, 4 = its staggered two-group
+ * form, 5 = the library's choice + the row-panel kernel for the residual projections, 3 = timing probe (variant 2 without its main-loop LDS-DMA: wrong results).  A/B measurements and tests. */
 int dark_dbg_set_gemm_variant(int variant);
 int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                        const uint8_t* key_mask, void* out, int B, int N, int H, int HD, int max_pos,

@@ -99,6 +99,38 @@ def test_gemm_resid_and_swiglu(lib, dtype):
     np.testing.assert_allclose(act.cpu().double().numpy(), ref.numpy(), **_tol(dtype))
 
 
+@pytest.mark.parametrize("M,K", [(1, 192), (95, 192), (96, 384), (333, 768), (2049, 3072)])
+def test_gemm_rowpanel_resid_norm(lib, M, K):
+    """gemm_rowpanel.hip (variant 5; o_proj / down_proj + residual + RMSNorm in one launch): the fp32 residual is
+    bit-identical to the residual GEMM's, the normalised rows are the norm of that residual (fp64 reference within
+    bf16 rounding) and within 1 bf16 ulp of the separate rmsnorm kernel's; rows beyond M are never written."""
+    H = _hip()
+    d, eps = 768, 1e-6
+    g = torch.Generator().manual_seed(M * 7 + K)
+    A = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    W = (torch.randn(d, K, generator=g) * 0.05).bfloat16().to(DEV)
+    h0 = torch.randn(M + 2, d, generator=g).to(DEV)
+    gam = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    h1, h2 = h0.clone(), h0.clone()
+    x1 = torch.full((M + 2, d), 3.0, device=DEV, dtype=torch.bfloat16)
+    x2 = torch.full((M, d), 3.0, device=DEV, dtype=torch.bfloat16)
+    H.check(lib.dark_dbg_gemm_resid_norm(H.ptr(A), H.ptr(W), H.ptr(h1), H.ptr(gam), H.ptr(x1), M, K, eps, _s()))
+    H.check(lib.dark_dbg_gemm(H.DARK_BF16, 1, H.ptr(A), H.ptr(W), None, H.ptr(h2), M, d, K, d, _s()))
+    H.check(lib.dark_dbg_rmsnorm(H.DARK_BF16, H.ptr(h2), H.ptr(gam), H.ptr(x2), None, M, M, d, eps, _s()))
+    h3 = h0.clone()
+    H.check(lib.dark_dbg_gemm_resid_norm(H.ptr(A), H.ptr(W), H.ptr(h3), None, None, M, K, eps, _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(h1, h2) and torch.equal(h3, h2)
+    assert torch.equal(h1[M:], h0[M:]) and bool((x1[M:] == 3.0).all()), "rows beyond M must stay untouched"
+    ref = O.rms_norm(h1[:M].cpu(), gam.cpu(), eps)
+    np.testing.assert_allclose(x1[:M].cpu().float().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+    ulp = (x1[:M].view(torch.int16).int() - x2.view(torch.int16).int()).abs().max().item()
+    assert ulp <= 1
+    # shapes the kernel does not take are refused, not mis-run
+    assert lib.dark_dbg_gemm_resid_norm(H.ptr(A), H.ptr(W), H.ptr(h3), None, None, M, 64, eps, _s()) == H.DARK_ERR_ARG
+    assert lib.dark_dbg_gemm_resid_norm(H.ptr(A), H.ptr(W), H.ptr(h3), H.ptr(gam), None, M, K, eps, _s()) == H.DARK_ERR_ARG
+
+
 # --------------------------------------------------------------------------- elementwise
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_embed_and_rmsnorm(lib, dtype):
