@@ -207,12 +207,17 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv
 #pragma unroll
         for (int k2 = 0; k2 < NK2; ++k2) {
           if (2 * k2 < n_t) {
-            bf16x8 vb;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-              const int jt = 2 * k2 + (jj >> 2);
-              vb[jj] = jt < NT ? Vs[(jt * 16 + 4 * g + (jj & 3)) * LD + dt * 16 + li] : (bf16_t)0.f;
-            }
+            // B operand = V[key][dim] for this lane's dim (dt*16 + li) and the 8 keys of its P slots: two transposed
+            // LDS reads (ds_read_b64_tr_b16: each 16-lane group fetches a 4-key x 16-dim block row-wise and receives
+            // it column-wise; lane 4q+p of the group supplies the address of key q, dims 4p..4p+3) instead of eight
+            // 2-byte reads.  The wave is fully active here (wave-uniform loops and conditions only), as the
+            // instruction requires; an odd tile count leaves the upper half of the last slot at zero.
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            const T* vrow = Vs + (2 * k2 * 16 + 4 * g + (li >> 2)) * LD + dt * 16 + 4 * (li & 3);
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)vrow);
+            bf16x4 hi = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if (2 * k2 + 1 < NT) hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(vrow + 16 * LD));
+            const bf16x8 vb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[k2], vb, acc, 0, 0, 0);
           }
         }

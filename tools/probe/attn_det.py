@@ -2,6 +2,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dark_amd import _hip
+if len(sys.argv) > 1:  # an alternative build of the library (e.g. one with an older attn.hip linked in)
+    _hip.LIB_PATH = os.path.abspath(sys.argv[1])
 from dark_amd.modeling_dream_length import rope_tables
 lib = _hip.load(); dev = torch.device("cuda"); st = _hip.stream_ptr(dev)
 B, N, H, HD = 512, 46, 8, 96
