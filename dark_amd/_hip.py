@@ -119,6 +119,13 @@ SIGNATURES = {
     "dark_dbg_set_gemm_variant": (C.c_int, [C.c_int]),
     "dark_dbg_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dark_head_sample_workspace_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.c_int]),
+    "dark_head_sample_rows": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "dark_dbg_gemm_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                     C.c_void_p]),
     "dark_dbg_gemm_resid_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_float, C.c_void_p]),
     "dark_dbg_rmsnorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

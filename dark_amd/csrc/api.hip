@@ -254,6 +254,95 @@ int dark_lm_head_rows(const dark_model_desc* m, const float* hidden, const int32
   return lm_head_rows(m, hidden, src_rows, 1 << 30, M, workspace, workspace_bytes, logits, ldl, (hipStream_t)stream);
 }
 
+// ---- fused LM head + sampler (sample.hip "fused LM head", gemm256.hip EPI_HEAD)
+struct HeadFuseWs {
+  char* xn;        // [M, d] model dtype: normalised rows
+  char* records;   // [M, P] 16-byte slice records
+  int32_t* list;   // [M] rows the records could not finish
+  int32_t* counters;  // [4]: [0] = length of list
+  char* xn_f;      // [M, d]: the listed rows, gathered
+  int P;
+  size_t total;
+};
+static HeadFuseWs carve_head_fuse(const dark_model_desc* m, size_t M, char* base) {
+  HeadFuseWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
+  w.P = 4 * cdiv(m->vocab, 256);
+  w.xn = take(M * m->d * esize(m->dtype));
+  w.records = take(M * (size_t)w.P * 16);
+  w.list = (int32_t*)take(M * 4);
+  w.counters = (int32_t*)take(16);
+  w.xn_f = take(M * m->d * esize(m->dtype));
+  w.total = off;
+  return w;
+}
+
+// Can (and should) this call take the fused path?  bf16 model, temperature > 0, nucleus filter on, no top-k, enough
+// rows to fill the persistent GEMM; everything else runs dark_lm_head_rows + dark_sample_rows.
+static bool head_fuse_applies(const dark_model_desc* m, int M, float temperature, float top_p, int top_k,
+                              const float* logits, int64_t ldl) {
+  if (ldl % 4 != 0 || ((uintptr_t)logits & 15) != 0) return false;  // the fallback GEMM stores 16 bytes a lane
+  if (gemm_variant() == 1) return false;  // A/B hook: variant 1 = the unfused head
+  if (m->dtype != DARK_BF16 || !(temperature > 0.f) || !(top_p >= 0.f && top_p < 1.f)) return false;
+  if (top_k > 0 && top_k < m->vocab) return false;
+  if (M < 1024 || m->vocab > 32768 || m->vocab % 4 != 0 || m->d % 64 != 0) return false;  // (16-byte logit stores)
+  return head_gemm_supports(M, m->vocab, m->d);
+}
+
+__global__ void head_stats_kernel(const int32_t* counters, int32_t* stats, int M) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { stats[0] += M; stats[1] += counters[0]; }
+}
+
+static int head_sample_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int n_src, int M,
+                            void* workspace, size_t ws_bytes, float* logits, int64_t ldl, float temperature, float top_p,
+                            int top_k, int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
+                            uint32_t nthreads, float* conf, int64_t* x0, int32_t* stats, hipStream_t st) {
+  DARK_TRY(check_model(m));
+  if (M <= 0) return DARK_OK;
+  DARK_CHECK_ARG(hidden && workspace && logits && conf && x0, "head_sample_rows: null pointer");
+  DARK_CHECK_ARG(ldl >= m->vocab, "head_sample_rows: ldl=%lld < vocab=%d", (long long)ldl, m->vocab);
+  const int V = m->vocab;
+  if (!head_fuse_applies(m, M, temperature, top_p, top_k, logits, ldl)) {
+    DARK_TRY(lm_head_rows(m, hidden, src_rows, n_src, M, workspace, ws_bytes, logits, ldl, st));
+    return launch_sample_indexed(logits, ldl, M, V, temperature, top_p, top_k, conf_mode, nullptr, noise, ldn, seed, offset,
+                                 nthreads, conf, x0, st);
+  }
+  HeadFuseWs w = carve_head_fuse(m, (size_t)M, (char*)workspace);
+  DARK_CHECK_ARG(ws_bytes >= w.total, "head_sample_rows: workspace %zu < required %zu bytes", ws_bytes, w.total);
+  const int w_rows = cdiv(V, 128) * 128;
+  DARK_CHECK_HIP(hipMemsetAsync(w.counters, 0, 16, st));
+  DARK_TRY(launch_rmsnorm(m->dtype, hidden, m->final_norm, w.xn, src_rows, n_src, M, m->d, m->rms_eps, st));
+  DARK_TRY(launch_gemm_head(w.xn, m->lm_head, w.records, M, V, m->d, head_c2(temperature), head_range_raw(temperature),
+                            nullptr, w_rows, st));
+  DARK_TRY(launch_head_finish(w.records, w.P, M, V, m->d, w.xn, m->lm_head, temperature, top_p, conf_mode, noise, ldn, seed,
+                              offset, nthreads, conf, x0, w.list, w.counters, st));
+  // the rows on the list: plain head GEMM + full sampler, sized on the device (no host round trip)
+  DARK_TRY(launch_gather_listed_rows(w.xn, w.list, w.counters, w.xn_f, m->d, M, st));
+  DARK_TRY(launch_gemm_s256_devrows(w.xn_f, m->lm_head, logits, M, V, m->d, ldl, w.counters, w_rows, st));
+  DARK_TRY(launch_sample_indexed(logits, ldl, M, V, temperature, top_p, top_k, conf_mode, w.list, noise, ldn, seed, offset,
+                                 nthreads, conf, x0, st, w.counters));
+  if (stats) {
+    hipLaunchKernelGGL(head_stats_kernel, dim3(1), dim3(64), 0, st, w.counters, stats, M);
+    DARK_CHECK_LAUNCH();
+  }
+  return DARK_OK;
+}
+
+size_t dark_head_sample_workspace_bytes(const dark_model_desc* m, int M) {
+  if (!m || M <= 0 || m->d <= 0 || m->vocab <= 0) return 0;
+  return carve_head_fuse(m, (size_t)M, nullptr).total;
+}
+
+int dark_head_sample_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M, void* workspace,
+                          size_t workspace_bytes, float* logits, int64_t ldl, float temperature, float top_p, int top_k,
+                          int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
+                          uint32_t nthreads, float* conf, int64_t* x0, int32_t* stats, void* stream) {
+  DARK_CHECK_ARG(nthreads == 0 || nthreads % 256 == 0, "head_sample_rows: nthreads=%u must be a multiple of 256", nthreads);
+  return head_sample_rows(m, hidden, src_rows, 1 << 30, M, workspace, workspace_bytes, logits, ldl, temperature, top_p,
+                          top_k, conf_mode, noise, ldn, seed, offset, nthreads, conf, x0, stats, (hipStream_t)stream);
+}
+
 int dark_noalloc_init(void) {
   void* p = nullptr;
   return scratch_on_current_device(&p);
@@ -411,6 +500,12 @@ int dark_dbg_set_gemm_variant(int variant) {
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                   int64_t ldo, void* stream) {
   return launch_gemm(dtype, epi, A, W, bias, out, M, N, K, ldo, (hipStream_t)stream);
+}
+int dark_dbg_gemm_head(const void* A, const void* W, void* records, int M, int N, int K, float temperature,
+                       const int32_t* m_dev, void* stream) {
+  DARK_CHECK_ARG(temperature > 0.f, "dbg_gemm_head: temperature must be positive");
+  return launch_gemm_head(A, W, records, M, N, K, head_c2(temperature), head_range_raw(temperature), m_dev,
+                          cdiv(N, 128) * 128, (hipStream_t)stream);
 }
 int dark_dbg_gemm_resid_norm(const void* A, const void* W, float* hidden, const float* ln_w, void* xn, int M, int K,
                              float eps, void* stream) {

@@ -132,7 +132,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // ---- launchers implemented across the .hip files --------------------------
 // GEMM epilogues: C[M,N] = A[M,K] * W[N,K]^T (+...)
-enum Epi { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_F32 = 3, EPI_LSE = 4 };
+enum Epi { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_F32 = 3, EPI_LSE = 4, EPI_HEAD = 5 };
 
 // A: [M,K] dtype, W: [Npad,K] dtype (rows padded to a multiple of 128 with zeros).
 // EPI_BIAS  : out (dtype) [M,ldo] = acc + bias[n]
@@ -151,6 +151,21 @@ int launch_gemm_p256(int epi, const void* A, const void* W, const float* bias, v
 bool s256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias);
 int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                      int64_t ldo, int w_rows, hipStream_t st);
+// EPI_HEAD (gemm_bf16_s256 only): no logits are written; per (row, 64-column slice) one 16-byte record
+// {max logit, sum over the slice's OTHER columns of exp2((l - max) * c2), count of columns within `range` of the max
+// | column of the max << 16, 0} into records[M][P], P = 4 * ceil(N / 256).  m_dev (nullable): the row count is read
+// from device memory (min(M, *m_dev)); launched for at most M rows.
+struct HeadSliceRec { float smax, tsum; int nn_col, pad; };
+// temperature -> the two epilogue constants: log2(e) / T, and the raw-logit width that is sure to cover the sampler's
+// head range (6.0 in units of logit / T) with every rounding of l / T on the safe side
+static inline float head_c2(float T) { return 1.4426950408889634f / T; }
+static inline float head_range_raw(float T) { return 6.0f * T * 1.001f; }
+bool head_gemm_supports(int M, int N, int K);
+int launch_gemm_head(const void* A, const void* W, void* records, int M, int N, int K, float c2, float range,
+                     const int* m_dev, int w_rows, hipStream_t st);
+// the EPI_F32 flavour of the same kernel with the row count read from device memory (fallback rows of the fused head)
+int launch_gemm_s256_devrows(const void* A, const void* W, void* out, int M, int N, int K, int64_t ldo, const int* m_dev,
+                             int w_rows, hipStream_t st);
 void set_gemm_variant(int v);
 int gemm_variant();
 // gemm_rowpanel.hip: hidden[M,768] += A[M,K] W[768,K]^T (fp32 residual, in place) and, with ln_w / xn non-null,
@@ -189,7 +204,15 @@ int launch_sample_philox(const float* logits, int64_t ldl, int M, int V, float t
 // `row_ids` nullable: logits is a compact list of rows row_ids[i] of the [M, V] problem (noise / Philox index / outputs)
 int launch_sample_indexed(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
                           int conf_mode, const int32_t* row_ids, const float* noise, int64_t ldn, uint64_t seed,
-                          uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st);
+                          uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st,
+                          const int32_t* n_dev = nullptr);
+// fused head (sample.hip): finish the rows from the slice records of launch_gemm_head; rows that cannot be finished are
+// appended to list[counters[0]++]
+int launch_head_finish(const void* records, int P, int M, int V, int K, const void* xn, const void* W, float temperature,
+                       float top_p, int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
+                       uint32_t nthreads, float* conf, int64_t* x0, int32_t* list, int32_t* counters, hipStream_t st);
+int launch_gather_listed_rows(const void* xn, const int32_t* list, const int32_t* n_dev, void* out, int d, int M,
+                              hipStream_t st);
 // vocabulary-sharded head (sample.hip)
 int launch_shard_row_max(const float* logits, int64_t ldl, int M, int Vs, float temperature, float* mx, hipStream_t st);
 int launch_shard_partials(const float* logits, int64_t ldl, int M, int Vs, int col0, float temperature,

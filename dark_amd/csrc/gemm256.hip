@@ -269,6 +269,7 @@ template <int EPI> struct StoresPerTile;                                   // bu
 template <> struct StoresPerTile<EPI_SWIGLU> { static constexpr int N = 8; };
 template <> struct StoresPerTile<EPI_BIAS> { static constexpr int N = 16; };
 template <> struct StoresPerTile<EPI_F32> { static constexpr int N = 32; };
+template <> struct StoresPerTile<EPI_HEAD> { static constexpr int N = 8; };
 constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }  // vmcnt(n), nothing else
 }  // namespace
 
@@ -276,9 +277,16 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ bias, void* __restrict__ out, int M,
                                                       int N, int K, int64_t ldo, int tilesM, int tilesN, int ntiles,
-                                                      unsigned a_bytes, unsigned w_bytes, unsigned o_bytes) {
+                                                      unsigned a_bytes, unsigned w_bytes, unsigned o_bytes,
+                                                      const int* __restrict__ m_dev, float hp_c2, float hp_range) {
   constexpr int GM = 8;
   constexpr int NST = StoresPerTile<EPI>::N;
+  if (m_dev) {  // row count from device memory (never more than the host's M, which sized the buffers)
+    const int md = __builtin_amdgcn_readfirstlane(*m_dev);
+    M = md < M ? (md > 0 ? md : 0) : M;
+    tilesM = (M + 255) >> 8;
+    ntiles = tilesM * tilesN;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -396,6 +404,55 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
           const unsigned off = (m < M && c + 8 <= N) ? (unsigned)(((int64_t)m * ldo + c) * 2) : 0xF0000000u;
           __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){sx[0], sy[0], sx[1], sy[1]}, ro, off, 0, 0);
         }
+      } else if constexpr (EPI == EPI_HEAD) {
+        // No logits leave the kernel: the row's 64 columns of this wave (16 per lane, 4 lanes per row) are reduced to
+        // {max, column of the max (lowest among equals), how many columns lie within hp_range of it, sum over the
+        // other columns of exp2((l - max) * hp_c2)}.  The max itself contributes exactly exp2(0) = 1 to the sum and
+        // is taken out afterwards; columns >= N (zero weight rows) count as -inf.
+        const int nb = n0 + wn * 64;
+        float l[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) l[k] = acc[k >> 2][mi][k & 3];
+        if (nb + 64 > N) {  // wave-uniform: only the last column tile
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (nb + (k >> 2) * 16 + 4 * fq + (k & 3) >= N) l[k] = -INFINITY;
+        }
+        float mxl = l[0];
+        int ik = 0;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {  // columns grow with k: a strict compare keeps the lowest among equals
+          const bool gt = l[k] > mxl;
+          mxl = gt ? l[k] : mxl;
+          ik = gt ? k : ik;
+        }
+        int col = (ik >> 2) * 16 + 4 * fq + (ik & 3);
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+          const float om = __shfl_xor(mxl, o, 64);
+          const int oc = __shfl_xor(col, o, 64);
+          const bool take = om > mxl || (om == mxl && oc < col);
+          mxl = take ? om : mxl;
+          col = take ? oc : col;
+        }
+        const bool any = mxl > -INFINITY;
+        const float thr = mxl - (hp_range + 2e-6f * fabsf(mxl));  // (the slack covers the roundings of l / T, see sample.hip)
+        float sum = 0.f;
+        int nn = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          sum += __builtin_amdgcn_exp2f((l[k] - mxl) * hp_c2);  // (-inf - finite) * c2 = -inf -> 0
+          nn += l[k] > thr ? 1 : 0;
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        nn += __shfl_xor(nn, 16, 64);
+        nn += __shfl_xor(nn, 32, 64);
+        const float tsum = any ? sum - 1.0f : 0.f;
+        const int P = tilesN * 4;
+        const unsigned off = (m < M && fq == 0 && nb < N) ? (unsigned)(((int64_t)m * P + (nb >> 6)) * 16) : 0xF0000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(
+            (u32x4_t){__float_as_uint(mxl), __float_as_uint(tsum), (unsigned)((any ? nn : 0) | (col << 16)), 0u}, ro, off, 0, 0);
       } else {  // EPI_F32
 #pragma unroll
         for (int ni = 0; ni < P_NI; ++ni) {
@@ -546,12 +603,69 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
     static SmemOptIn optin;                                                                                        \
     DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<E>, smem, st));                                              \
     hipLaunchKernelGGL((gemm_bf16_s256<E>), dim3(grid), dim3(512), smem, st, (const bf16_t*)A, (const bf16_t*)W,   \
-                       bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes);                \
+                       bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes,                 \
+                       (const int*)nullptr, 0.f, 0.f);                                                             \
   }
   if (epi == EPI_SWIGLU) DARK_S256(EPI_SWIGLU)
   else if (epi == EPI_BIAS) DARK_S256(EPI_BIAS)
   else DARK_S256(EPI_F32)
 #undef DARK_S256
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+// ---- fused LM head: the EPI_HEAD flavour (slice records instead of logits) and the plain fp32 flavour with a
+// device-side row count (the rows the records could not finish)
+bool head_gemm_supports(int M, int N, int K) {
+  if (M <= 0 || N < 256 || K % 64 != 0 || K < 128) return false;
+  if ((int64_t)M * K * 2 >= (1ll << 31) || ((int64_t)N + 256) * K * 2 >= (1ll << 31)) return false;
+  if (((int64_t)M + 256) * (cdiv(N, 256) * 4) * 16 >= 0xE0000000ll) return false;
+  return true;
+}
+
+static int cu_count(int* cus) {
+  int dev = 0;
+  DARK_CHECK_HIP(hipGetDevice(&dev));
+  DARK_CHECK_HIP(hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev));
+  return DARK_OK;
+}
+
+int launch_gemm_head(const void* A, const void* W, void* records, int M, int N, int K, float c2, float range,
+                     const int* m_dev, int w_rows, hipStream_t st) {
+  DARK_CHECK_ARG(A && W && records && head_gemm_supports(M, N, K), "gemm_head: unsupported shape M=%d N=%d K=%d", M, N, K);
+  DARK_CHECK_ARG(((uintptr_t)records & 15) == 0 && c2 > 0.f && range > 0.f, "gemm_head: bad argument");
+  const int tilesM = cdiv(M, 256), tilesN = cdiv(N, 256);
+  const int ntiles = tilesM * tilesN;
+  int cus = 0;
+  DARK_TRY(cu_count(&cus));
+  const int grid = min(ntiles, cus);
+  const unsigned a_bytes = (unsigned)((int64_t)M * K * 2), w_bytes = (unsigned)((int64_t)w_rows * K * 2);
+  const unsigned o_bytes = (unsigned)((int64_t)M * tilesN * 4 * 16);
+  static SmemOptIn optin;
+  DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<EPI_HEAD>, S_SMEM, st));
+  hipLaunchKernelGGL((gemm_bf16_s256<EPI_HEAD>), dim3(grid), dim3(512), S_SMEM, st, (const bf16_t*)A, (const bf16_t*)W,
+                     (const float*)nullptr, records, M, N, K, (int64_t)0, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes,
+                     m_dev, c2, range);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+int launch_gemm_s256_devrows(const void* A, const void* W, void* out, int M, int N, int K, int64_t ldo, const int* m_dev,
+                             int w_rows, hipStream_t st) {
+  DARK_CHECK_ARG(s256_supports(EPI_F32, M, N, K, ldo, out, nullptr) && m_dev, "gemm_s256_devrows: unsupported shape M=%d N=%d K=%d",
+                 M, N, K);
+  const int tilesM = cdiv(M, 256), tilesN = cdiv(N, 256);
+  const int ntiles = tilesM * tilesN;
+  int cus = 0;
+  DARK_TRY(cu_count(&cus));
+  const int grid = min(ntiles, cus);
+  const unsigned a_bytes = (unsigned)((int64_t)M * K * 2), w_bytes = (unsigned)((int64_t)w_rows * K * 2);
+  const unsigned o_bytes = (unsigned)((int64_t)M * ldo * 4);
+  static SmemOptIn optin;
+  DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<EPI_F32>, S_SMEM, st));
+  hipLaunchKernelGGL((gemm_bf16_s256<EPI_F32>), dim3(grid), dim3(512), S_SMEM, st, (const bf16_t*)A, (const bf16_t*)W,
+                     (const float*)nullptr, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes, m_dev, 0.f,
+                     0.f);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }

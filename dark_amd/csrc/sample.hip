@@ -485,8 +485,10 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
                                                     float temperature, float top_p, int top_k, int conf_mode,
                                                     const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
                                                     float* __restrict__ conf, int64_t* __restrict__ x0,
-                                                    const int32_t* __restrict__ row_ids) {
+                                                    const int32_t* __restrict__ row_ids,
+                                                    const int32_t* __restrict__ n_dev) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (n_dev && (int)blockIdx.x >= *n_dev) return;  // row count from device memory (block-uniform)
   const int vp = (V + 3) & ~3;
   float* row = (float*)smem;
   unsigned long long* hist = (unsigned long long*)(smem + (size_t)vp * 4);  // NLIN u64; radix hist/cnt alias it
@@ -773,12 +775,13 @@ int launch_sample_philox(const float* logits, int64_t ldl, int M, int V, float t
                          int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
                          uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st) {
   return launch_sample_indexed(logits, ldl, M, V, temperature, top_p, top_k, conf_mode, nullptr, noise, ldn, seed, offset,
-                               nthreads, conf, x0, st);
+                               nthreads, conf, x0, st, nullptr);
 }
 
 int launch_sample_indexed(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p, int top_k,
                           int conf_mode, const int32_t* row_ids, const float* noise, int64_t ldn, uint64_t seed,
-                          uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st) {
+                          uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st,
+                          const int32_t* n_dev) {
   if (M <= 0) return DARK_OK;
   DARK_CHECK_ARG(V >= 2 && V <= 32768, "sample_rows: V=%d must be in [2, 32768]", V);
   DARK_CHECK_ARG(ldl >= V, "sample_rows: ldl < V");
@@ -794,7 +797,7 @@ int launch_sample_indexed(const float* logits, int64_t ldl, int M, int V, float 
   static SmemOptIn optin;
   DARK_TRY(optin.ensure((const void*)sample_kernel, smem, st));
   hipLaunchKernelGGL(sample_kernel, dim3(M), dim3(ST), smem, st, logits, ldl, V, temperature, top_p, top_k,
-                     conf_mode, noise, ldn, pn, conf, x0, row_ids);
+                     conf_mode, noise, ldn, pn, conf, x0, row_ids, n_dev);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }
@@ -969,6 +972,214 @@ int launch_sample_from_shards(const void* parts, int64_t ldp, int S, int M, int 
   const PhiloxNoise pn{seed, offset, nthreads};
   hipLaunchKernelGGL(sample_from_shards_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const ShardPart*)parts, ldp, S, M, V,
                      temperature, top_p, top_k, conf_mode, mx, noise, ldn, pn, conf, x0, flags);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+// ================================================================== fused LM head: finishing the rows from slice records
+// gemm_bf16_s256<EPI_HEAD> leaves, per masked row and 64-column slice of the vocabulary, {max logit, its column, how
+// many columns lie within the head range of it, sum over the other columns of exp((l - max) / T)} instead of logits
+// (16 B per slice: 3.8 KB per row at V = 15080 against 60 KB of fp32 logits).  One wave per row turns them into what
+// sample_kernel's head path computes, bit for bit:
+//   * row maximum = max of the slice maxima; the head set (logit / T within HEAD_RANGE of it) can only contain the
+//     maxima of "hot" slices (max within the raw-space range of the row maximum) and, where a hot slice counted more
+//     than one column in range, other columns of that slice: those 64 logits are RECOMPUTED here with the GEMM's own
+//     MFMA chain (same operands, same K order: the same bits) and examined one by one;
+//   * head candidates get their exact 2^-40 fixed-point masses; every other column's mass is only needed inside the
+//     total Z that sets the nucleus threshold T = floor(top_p * Z): slice maxima outside the head set are added
+//     exactly, the rest is bounded from the slice sums, Z in [Z_lo, Z_hi], with margins that cover the float
+//     evaluation (relative 2e-3 + the rounding of l / T), the summation order (2^-17 per slice) and the truncation of
+//     the per-element masses (one unit each);
+//   * if T(Z_lo) and T(Z_hi) give the same crossing element and the same number of kept ties, every Z in between --
+//     the exact one included -- gives the kept set the unfused sampler finds; list_tail_wave then does softmax,
+//     confidence and the Philox draw on that set exactly as there.  Otherwise (and for more than 64 candidates, more
+//     than 8 slices to recompute, a head set that does not hold top_p of the mass) the row is appended to a list; the
+//     caller runs the plain head GEMM and sample_kernel for the listed rows (dark_head_sample_rows).
+namespace {
+constexpr int HF_MAXRE = 8;  // hot slices with more than one column in range that a row may recompute
+struct HeadFinishLds {
+  unsigned long long cfx[64];
+  uint32_t cand[64];
+  int cidx[64];
+  int re[HF_MAXRE];
+};
+}  // namespace
+
+__global__ __launch_bounds__(256) void head_finish_kernel(const HeadSliceRec* __restrict__ rec, int P, int M, int V, int K,
+                                                          const bf16_t* __restrict__ xn, const bf16_t* __restrict__ W,
+                                                          float temperature, float top_p, int conf_mode, float c2,
+                                                          float range_raw, const float* __restrict__ noise, int64_t ldn,
+                                                          PhiloxNoise pn, float* __restrict__ conf,
+                                                          int64_t* __restrict__ x0, int32_t* __restrict__ list,
+                                                          int32_t* __restrict__ counters) {
+  __shared__ HeadFinishLds lds_all[4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + w;
+  if (m >= M) return;  // wave-uniform
+  HeadFinishLds& L = lds_all[w];
+  const HeadSliceRec* r = rec + (int64_t)m * P;
+  // ---- pass 1: row maximum (raw logits)
+  float lmax = -INFINITY;
+  for (int p = lane; p < P; p += 64) lmax = fmaxf(lmax, r[p].smax);
+  lmax = wave_max(lmax);
+  const float mx = lmax / temperature;  // the sampler's scaled maximum: the same division on the same value
+  const float hot_thr = lmax - (range_raw + 2e-6f * fabsf(lmax));
+  // ---- pass 2: classify the slices
+  int c = 0, nre = 0;            // head candidates, slices to recompute (wave-uniform)
+  bool fail = !(lmax > -INFINITY) || !(lmax < INFINITY);
+  unsigned long long tail_exact = 0;  // masses known exactly that are not head candidates (per lane, summed later)
+  double tail_f = 0.0, slack = 0.0;   // bounded part, in units of the maximum's mass
+  for (int p0 = 0; p0 < P; p0 += 64) {
+    const int p = p0 + lane;
+    float smax = -INFINITY, tsum = 0.f;
+    int nn = 0, col = 0;
+    if (p < P) { const HeadSliceRec q = r[p]; smax = q.smax; tsum = q.tsum; nn = q.nn_col & 0xffff; col = q.nn_col >> 16; }
+    const bool live = smax > -INFINITY;
+    const bool hot = live && smax > hot_thr;
+    const bool redo = hot && nn >= 2;
+    if (live && !redo) {
+      const float wgt = __builtin_amdgcn_exp2f((smax - lmax) * c2);
+      tail_f += (double)wgt * (double)tsum;
+      slack += (double)wgt * (double)(tsum + 1.0f) * (1.0 / 131072.0);
+    }
+    // this slice's maximum: head candidate or exact tail mass (a slice that is recomputed handles its own maximum)
+    const float sc = smax / temperature;
+    const bool is_head = live && !redo && (sc - mx > -HEAD_RANGE);
+    if (live && !redo && !is_head) tail_exact += mass_fx(sc, mx);
+    const unsigned long long hb = __ballot(is_head), rb = __ballot(redo);
+    const int hpos = c + __popcll(hb & ((1ull << lane) - 1ull));
+    if (is_head && hpos < 64) { L.cand[hpos] = fkey(sc); L.cfx[hpos] = mass_fx(sc, mx); L.cidx[hpos] = p * 64 + col; }
+    c += __popcll(hb);
+    const int rpos = nre + __popcll(rb & ((1ull << lane) - 1ull));
+    if (redo && rpos < HF_MAXRE) L.re[rpos] = p;
+    nre += __popcll(rb);
+  }
+  if (c > 64 || nre > HF_MAXRE) fail = true;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // ---- recompute the marked slices: logits[m][64 p .. 64 p + 63] = xn[m] . W[col] with the GEMM's MFMA chain
+  if (!fail && nre > 0) {
+    const int frow = lane & 15, fq = lane >> 4;
+    const bf16_t* arow = xn + (int64_t)m * K + fq * 8;  // every MFMA row is this row: all 16 result rows are equal
+    for (int i = 0; i < nre; ++i) {
+      const int p = L.re[i];
+      f32x4 acc[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const bf16_t* wrow = W + (int64_t)(p * 64 + frow) * K + fq * 8;
+      for (int kt = 0; kt < K / 32; ++kt) {
+        const bf16x8 fa = *(const bf16x8*)(arow + kt * 32);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const bf16x8 fw = *(const bf16x8*)(wrow + (int64_t)ni * 16 * K + kt * 32);
+          acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fa, acc[ni], 0, 0, 0);
+        }
+      }
+      // lane (frow, fq) holds columns 64 p + 16 ni + 4 fq + e of row `frow` of the tile (= this row); lanes with
+      // frow == 0 speak for the slice
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int colg = p * 64 + (k >> 2) * 16 + 4 * fq + (k & 3);
+        const float sc = acc[k >> 2][k & 3] / temperature;
+        const bool val = frow == 0 && colg < V;
+        const bool is_head = val && (sc - mx > -HEAD_RANGE);
+        if (val && !is_head) tail_exact += mass_fx(sc, mx);
+        const unsigned long long hb = __ballot(is_head);
+        const int hpos = c + __popcll(hb & ((1ull << lane) - 1ull));
+        if (is_head && hpos < 64) { L.cand[hpos] = fkey(sc); L.cfx[hpos] = mass_fx(sc, mx); L.cidx[hpos] = colg; }
+        c += __popcll(hb);
+      }
+    }
+    if (c > 64) fail = true;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  // ---- Z interval, threshold interval, certification of the crossing
+  unsigned long long T_hi = 0;
+  if (!fail) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      tail_exact += __shfl_xor(tail_exact, o, 64);
+      tail_f += __shfl_xor(tail_f, o, 64);
+      slack += __shfl_xor(slack, o, 64);
+    }
+    unsigned long long hl = lane < c ? L.cfx[lane] : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) hl += __shfl_xor(hl, o, 64);
+    const double delta = 2e-3 + 4e-7 * ((double)fabsf(mx) + 30.0);
+    const double two40 = 1099511627776.0;
+    const double known = (double)hl + (double)tail_exact;  // exact integers below 2^53
+    double z_lo = known + (tail_f * (1.0 - delta) - slack) * two40 - (double)V;
+    const double z_hi = known + (tail_f * (1.0 + delta) + slack) * two40 + 1.0;
+    if (z_lo < known) z_lo = known;
+    const unsigned long long T_lo = (unsigned long long)((double)top_p * z_lo);
+    T_hi = (unsigned long long)((double)top_p * z_hi);
+    if (!(hl > T_hi) || c < 1) fail = true;
+    if (!fail) {  // tau / kept ties under both thresholds (list_tail_wave's own arithmetic)
+      const bool own = lane < c;
+      const uint32_t kj = own ? L.cand[lane] : 0u;
+      unsigned long long S = 0;
+      for (int i = 0; i < c; ++i) S += L.cand[i] >= kj ? L.cfx[i] : 0ull;
+      uint32_t tau_lo = (own && S > T_lo) ? kj : 0u, tau_hi = (own && S > T_hi) ? kj : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        tau_lo = max(tau_lo, (uint32_t)__shfl_xor((int)tau_lo, o, 64));
+        tau_hi = max(tau_hi, (uint32_t)__shfl_xor((int)tau_hi, o, 64));
+      }
+      if (tau_lo != tau_hi) fail = true;
+      else {
+        unsigned long long above = (own && kj > tau_hi) ? L.cfx[lane] : 0ull, nt = (own && kj == tau_hi) ? 1ull : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { above += __shfl_xor(above, o, 64); nt += __shfl_xor(nt, o, 64); }
+        if (nt > 1ull) {
+          const unsigned long long fx = mass_fx(fkey_inv(tau_hi), mx);
+          if (fx && (T_lo - above) / fx != (T_hi - above) / fx) fail = true;
+        }
+      }
+    }
+  }
+  if (fail) {
+    if (lane == 0) list[atomicAdd(&counters[0], 1)] = m;
+    return;
+  }
+  list_tail_wave(L.cand, L.cfx, L.cidx, c, T_hi, mx, V, temperature, conf_mode, noise ? noise + (int64_t)m * ldn : nullptr, pn,
+                 (unsigned long long)m * V, lane, conf + m, x0 + m);
+}
+
+// rows of xn listed in `list` (count read from device memory) -> out, 16 bytes a lane
+__global__ __launch_bounds__(256) void gather_listed_rows_kernel(const bf16_t* __restrict__ xn, const int32_t* __restrict__ list,
+                                                                 const int32_t* __restrict__ n_dev, bf16_t* __restrict__ out,
+                                                                 int d, int M) {
+  const int n = min(*n_dev, M);
+  const int per_row = d / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)n * per_row; i += (int64_t)gridDim.x * 256) {
+    const int rrow = (int)(i / per_row), ch = (int)(i - (int64_t)rrow * per_row);
+    int src = list[rrow];
+    src = src < 0 ? 0 : (src >= M ? M - 1 : src);
+    *(uint4*)(out + (int64_t)rrow * d + ch * 8) = *(const uint4*)(xn + (int64_t)src * d + ch * 8);
+  }
+}
+
+int launch_head_finish(const void* records, int P, int M, int V, int K, const void* xn, const void* W, float temperature,
+                       float top_p, int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
+                       uint32_t nthreads, float* conf, int64_t* x0, int32_t* list, int32_t* counters, hipStream_t st) {
+  if (M <= 0) return DARK_OK;
+  DARK_CHECK_ARG(records && xn && W && conf && x0 && list && counters, "head_finish: null pointer");
+  DARK_CHECK_ARG(temperature > 0.f && top_p >= 0.f && top_p < 1.f && conf_mode >= 0 && conf_mode <= 2 && K % 32 == 0,
+                 "head_finish: needs temperature > 0 and an active nucleus filter");
+  DARK_CHECK_ARG(nthreads > 0 || (noise && ldn >= V), "head_finish: needs noise [M,V] or a Philox state");
+  const PhiloxNoise pn{seed, offset, nthreads};
+  hipLaunchKernelGGL(head_finish_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, (const HeadSliceRec*)records, P, M, V, K,
+                     (const bf16_t*)xn, (const bf16_t*)W, temperature, top_p, conf_mode, head_c2(temperature),
+                     head_range_raw(temperature), noise, ldn, pn, conf, x0, list, counters);
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
+int launch_gather_listed_rows(const void* xn, const int32_t* list, const int32_t* n_dev, void* out, int d, int M,
+                              hipStream_t st) {
+  DARK_CHECK_ARG(xn && list && n_dev && out && d % 8 == 0 && M > 0, "gather_listed_rows: bad argument");
+  hipLaunchKernelGGL(gather_listed_rows_kernel, dim3(512), dim3(256), 0, st, (const bf16_t*)xn, list, n_dev, (bf16_t*)out, d, M);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }

@@ -141,6 +141,16 @@ class HipState:
         self.count_event = torch.cuda.Event()
         self.head_ws = None
         self.logits = None
+        self.fuse_ws = None
+        # head_and_sample through dark_head_sample_rows (same results; see its header): True / False, or "auto" = on
+        # until the device-side statistics (read back without waiting) show that more than 30 % of the rows needed
+        # their logits anyway (flat distributions, e.g. random-init weights), then off for the next 256 calls
+        self.fused_head = "auto"
+        self.head_stats = torch.zeros(2, dtype=torch.int32, device=dev)  # [rows sampled, rows that needed their logits]
+        self.head_stats_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self.head_stats_event = None
+        self._stats_seen = (0, 0)
+        self._fuse_calls, self._fuse_off_until = 0, 0
         self.conf = torch.empty(rows, dtype=torch.float32, device=dev)
         self.x0 = torch.empty(rows, dtype=torch.int64, device=dev)
         self.hidden_rows = torch.empty((rows, cfg.hidden_size), dtype=torch.float32, device=dev)
@@ -218,8 +228,30 @@ class HipState:
         """`philox` = (seed, offset, nthreads) from generation_utils.philox_fill_plan: draws computed in the kernel.
         Reads hidden_rows[:M] (forward_begin + forward_rows) when it is current, else hidden[src_rows[:M]]."""
         V = self.cfg.vocab_size
-        logits = self.head_rows(None, M, self.hidden_rows) if self.rows_valid else self.head_rows(self.src_rows, M)
         conf, x0 = self.conf[:M], self.x0[:M]
+        if self._use_fused_head():
+            # dark_head_sample_rows: same conf / x0; logits are only materialised for the rows its records cannot finish
+            self._ensure_head(M)
+            ldl = (V + 3) & ~3   # 16-byte rows for the fallback GEMM's stores
+            if self.logits.numel() < M * ldl:
+                self.logits = torch.empty(M * ldl, dtype=torch.float32, device=self.pk.device)
+            need = self.lib.dark_head_sample_workspace_bytes(self.pk.ref, M)
+            if self.fuse_ws is None or self.fuse_ws.numel() < need:
+                self.fuse_ws = torch.empty(need, dtype=torch.uint8, device=self.pk.device)
+            hidden, src = (self.hidden_rows, None) if self.rows_valid else (self.hidden, self.src_rows)
+            seed, off, nth = philox if philox is not None else (0, 0, 0)
+            _hip.check(self.lib.dark_head_sample_rows(
+                self.pk.ref, _hip.ptr(hidden), _hip.ptr(src), M, _hip.ptr(self.fuse_ws), self.fuse_ws.numel(),
+                _hip.ptr(self.logits), ldl, float(temperature), float(top_p), int(top_k), int(conf_mode),
+                _hip.ptr(noise) if philox is None else None,
+                noise.stride(0) if (noise is not None and philox is None) else 0, seed, off, nth, _hip.ptr(conf),
+                _hip.ptr(x0), _hip.ptr(self.head_stats), self._s()))
+            if self.fused_head == "auto" and self.head_stats_event is None:
+                self.head_stats_host.copy_(self.head_stats, non_blocking=True)
+                self.head_stats_event = torch.cuda.Event()
+                self.head_stats_event.record(torch.cuda.current_stream(self.pk.device))
+            return conf, x0
+        logits = self.head_rows(None, M, self.hidden_rows) if self.rows_valid else self.head_rows(self.src_rows, M)
         if philox is not None:
             _hip.check(self.lib.dark_sample_rows_philox(_hip.ptr(logits), V, M, V, float(temperature), float(top_p),
                                                         int(top_k), int(conf_mode), philox[0], philox[1], philox[2],
@@ -230,6 +262,19 @@ class HipState:
                                              noise.stride(0) if noise is not None else 0, _hip.ptr(conf),
                                              _hip.ptr(x0), self._s()))
         return conf, x0
+
+    def _use_fused_head(self) -> bool:
+        if self.fused_head != "auto":
+            return bool(self.fused_head)
+        self._fuse_calls += 1
+        ev = self.head_stats_event
+        if ev is not None and ev.query():   # never waits: a read-back that has not landed is looked at next time
+            rows, fb = int(self.head_stats_host[0]), int(self.head_stats_host[1])
+            d_rows, d_fb = rows - self._stats_seen[0], fb - self._stats_seen[1]
+            self._stats_seen, self.head_stats_event = (rows, fb), None
+            if d_rows > 0 and d_fb > 0.3 * d_rows:
+                self._fuse_off_until = self._fuse_calls + 256
+        return self._fuse_calls >= self._fuse_off_until
 
     def sample_into(self, logits, n, temperature, top_p, top_k, conf_mode, noise, philox):
         """dark_sample_rows(_philox) on `logits` [n, V] into the state's conf / x0 buffers."""

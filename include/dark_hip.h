@@ -346,6 +346,30 @@ int dark_prof_read(double* total_ms, double* total_flops, int* launches);
  *        float [M] target logits.  W has rows padded to 128. */
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                   int N, int K, int64_t ldo, void* stream);
+/* LM head + sampler for the M masked rows in one call, without materialising the logits where that is possible.
+ * Same inputs and the same conf / x0, bit for bit, as dark_lm_head_rows followed by dark_sample_rows(_philox)
+ * (modeling_dream_length.py:809 + generation_utils.py:58-90).  For a bf16 model with temperature > 0, an active
+ * nucleus filter (0 <= top_p < 1), no top-k, a vocabulary that is a multiple of 4 and M >= 1024 the head GEMM's epilogue reduces every 64-column slice of
+ * a row to a 16-byte record (maximum, its column, columns in the head range, sum of the other columns' exp), one
+ * wave per row rebuilds the sampler's head set from the records (recomputing single slices with the GEMM's own MFMA
+ * chain where a slice holds more than one candidate), bounds the total mass Z from both sides and finishes the row
+ * when the nucleus crossing is the same for every Z in the interval; rows it cannot certify (flat distributions) get
+ * their logits from a second, device-sized GEMM into `logits` and go through the full sampler.  Every other case runs
+ * the two-call form (so does an ldl that is not a multiple of 4).  `logits` [M, ldl] fp32 is scratch either way.  noise [M, ldn] or a Philox state (nthreads > 0) as
+ * in dark_sample_rows(_philox).  stats (device int32[2], nullable): [0] += M, [1] += rows that took the fallback.
+ * workspace: dark_head_sample_workspace_bytes(m, M) (>= what dark_lm_head_rows needs). */
+size_t dark_head_sample_workspace_bytes(const dark_model_desc* m, int M);
+int dark_head_sample_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M, void* workspace,
+                          size_t workspace_bytes, float* logits, int64_t ldl, float temperature, float top_p, int top_k,
+                          int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
+                          uint32_t nthreads, float* conf, int64_t* x0, int32_t* stats, void* stream);
+/* The LM-head GEMM flavour of the fused head + sampler (dark_head_sample_rows): logits[M,N] = A[M,K] * W[N,K]^T are
+ * reduced in the epilogue to one 16-byte record per (row, 64-column slice) -- {max logit, sum over the slice's other
+ * columns of exp((l - max) / T), (count of columns within the sampler's head range of the max) | (column of the max
+ * within the slice) << 16, 0} -- records[M][4 * ceil(N / 256)]; no logits are written.  m_dev (nullable): row count
+ * read from device memory.  W rows padded to a multiple of 128.  Test hook. */
+int dark_dbg_gemm_head(const void* A, const void* W, void* records, int M, int N, int K, float temperature,
+                       const int32_t* m_dev, void* stream);
 /* The row-panel kernel that variant 5 of dark_dbg_set_gemm_variant puts behind the forward's o_proj / down_proj for
  * bf16 models of width 768 (gemm_rowpanel.hip; not the default):
  * hidden[M,768] (fp32, in place) += A[M,K] * W[768,K]^T and, when ln_w and xn are given (both or neither),
