@@ -287,7 +287,8 @@ static bool head_fuse_applies(const dark_model_desc* m, int M, float temperature
   if (m->dtype != DARK_BF16 || !(temperature > 0.f) || !(top_p >= 0.f && top_p < 1.f)) return false;
   if (top_k > 0 && top_k < m->vocab) return false;
   if (M < 1024 || m->vocab > 32768 || m->vocab % 4 != 0 || m->d % 64 != 0) return false;  // (16-byte logit stores)
-  return head_gemm_supports(M, m->vocab, m->d);
+  // (the fallback GEMM addresses the logits with 32-bit byte offsets: very large M x V takes the two-call form)
+  return head_gemm_supports(M, m->vocab, m->d) && s256_supports(EPI_F32, M, m->vocab, m->d, ldl, logits, nullptr);
 }
 
 __global__ void head_stats_kernel(const int32_t* counters, int32_t* stats, int M) {
