@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the bf16 GEMM kernels in ONE process (interleaved rounds, same device, random operands): variant 1 = the
-128-row kernels of gemm.hip, variant 2 = the persistent 256 x 256 kernel of gemm256.hip.  Checks variant 2 against an
+128-row kernels of gemm.hip, 2 = the persistent 256 x 256 kernel of gemm256.hip, 4 = its staggered form
+(a variant serves the shapes it supports and falls back to variant 1 elsewhere).  Checks variant 2 against an
 fp64 reference on ragged row counts first.  Usage (GPU box): python tools/gemm_ab.py [--rows 23552] [--rounds 5]"""
 import argparse
 import os
@@ -32,7 +33,7 @@ def main():
     st = _hip.stream_ptr(dev)
     g = torch.Generator().manual_seed(0)
     shapes = [("gate/up swiglu", 2, 6144, 768), ("qkv+bias", 0, 2304, 768), ("lm_head f32", 3, 15080, 768),
-              ("gate/up K3072", 2, 6144, 3072)]
+              ("gate/up K3072", 2, 6144, 3072), ("o_proj resid", 1, 768, 768), ("down resid", 1, 768, 3072)]
     for name, epi, N, K in shapes:
         if args.only and args.only not in name:
             continue
@@ -52,10 +53,13 @@ def main():
                 ldo, odt = N // 2, torch.bfloat16
             else:
                 ldo, odt = N, torch.float32
+            base = torch.randn(M, ldo, generator=g) if epi == 1 else None   # the residual stream the GEMM adds to
+            if epi == 1:
+                ref = ref + base.double()
             outs = []
             for v in variants:
-                lib.dark_dbg_set_gemm_variant(v)
-                out = torch.full((M, ldo), float("nan"), device=dev, dtype=odt)
+                _hip.check(lib.dark_dbg_set_gemm_variant(v))
+                out = base.to(dev).clone() if epi == 1 else torch.full((M, ldo), float("nan"), device=dev, dtype=odt)
                 _hip.check(lib.dark_dbg_gemm(1, epi, _hip.ptr(Ad), _hip.ptr(Wd), _hip.ptr(bd) if epi == 0 else None,
                                              _hip.ptr(out), M, N, K, ldo, st))
                 torch.cuda.synchronize()
@@ -71,12 +75,12 @@ def main():
         Wt = (torch.randn(pad_rows(torch.empty(N, 1)).shape[0], K, device=dev) * 0.05).bfloat16()
         bd = torch.randn(Wt.shape[0], device=dev)
         ldo = N // 2 if epi == 2 else N
-        o = torch.zeros(M, ldo, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
+        o = torch.zeros(M, ldo, device=dev, dtype=torch.float32 if epi in (1, 3) else torch.bfloat16)
         bptr = _hip.ptr(bd) if epi == 0 else None
         times = {v: [] for v in variants}
         for r in range(args.rounds + 1):
             for v in variants:
-                lib.dark_dbg_set_gemm_variant(v)
+                _hip.check(lib.dark_dbg_set_gemm_variant(v))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.iters):
