@@ -3,12 +3,16 @@
 // Replaces the nn.Linear calls of modeling_dream_length.py:381-383 (q/k/v + bias), :436 (o_proj,
 // + residual add :508), :221-222 (gate/up + SiLU*up, down + residual add :514) and :809 (lm_head).
 //
-// Both operands are K-contiguous ("B^T" layout = how nn.Linear stores weights), so A and W tiles
-// are staged identically.  Block tile 128x128, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles.
-//   bf16: v_mfma_f32_32x32x16_bf16, BK = 64, LDS rows of 128 B with a 16-B-chunk XOR swizzle
-//         (chunk ^= row & 7) so the ds_read_b128 fragment reads spread over the bank row.
-//   fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, k ascending), BK = 16, LDS rows padded to 17.
-// Double-buffered LDS, global loads of tile t+1 issued before the MFMAs of tile t (register staging).
+// Both operands are K-contiguous ("B^T" layout = how nn.Linear stores weights), so A and W tiles are staged
+// identically.  Kernels of this file:
+//   bf16: gemm_bf16_kernel16<EPI, BNt> -- 128 x BNt block tile (BNt = 192, or 128 for the fp32-out flavours), 4 waves
+//         (2 x 2) of v_mfma_f32_16x16x32_bf16 tiles, BK = 64, two LDS stages filled by LDS-DMA, two workgroups per CU.
+//         Serves q/k/v + bias, o_proj / down_proj + residual, the log-sum-exp head of the GRPO path, and every launch
+//         too small for the persistent 256 x 256 kernels of gemm256.hip (pick_kernel below decides).
+//   fp32: gemm_f32_kernel<EPI> -- 128 x 128 tile, 4 waves of 2 x 2 v_mfma_f32_32x32x2_f32 tiles (an exact fp32 fma chain
+//         per output, k ascending: what the bit-exact parity tests against the CPU oracle rely on), BK = 16, LDS rows
+//         padded to 17 floats, register-staged double buffering.
+// launch_gemm() is the single entry; the HIP-event timing hook of bench.py's roofline leg wraps it.
 
 #include <utility>
 #include <vector>

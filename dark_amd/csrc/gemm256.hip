@@ -1,8 +1,11 @@
-// Persistent 256 x 256 bf16 GEMM for the wide projections of the denoise forward (gate/up with the fused SwiGLU,
-// q/k/v with bias): C[M,N] = A[M,K] * W[N,K]^T, both operands K-contiguous.
+// Persistent 256 x 256 bf16 GEMMs for the wide projections of the denoise forward: C[M,N] = A[M,K] * W[N,K]^T, both
+// operands K-contiguous.  Two kernels: gemm_bf16_p256 (first form, kept as A/B variant 2) and gemm_bf16_s256 (the
+// staggered form further down: the one that runs).
 //
-// Replaces the same nn.Linear calls as gemm.hip (modeling_dream_length.py:221-222, :381-383) for the shapes where a
-// 256-wide macro tile quantises well; gemm.hip keeps the N = 768 residual GEMMs and the LM head.
+// Replaces the same nn.Linear calls as gemm.hip for the shapes where a 256-wide macro tile quantises well:
+// gate/up with the fused SwiGLU (modeling_dream_length.py:221-222) and the LM head (:809), incl. the fused head's
+// slice-record flavour (EPI_HEAD).  gemm.hip keeps q/k/v (N = 2304 leaves the fourth round of 256 x 256 tiles 23 %
+// full), the N = 768 residual GEMMs and every launch with fewer than 512 such tiles (pick_kernel in gemm.hip).
 //
 // Why another kernel: the 128 x 192 kernel of gemm.hip moves (128 + 192) * 128 B from L2 into LDS per 128*192*64
 // MACs and reads 10 fragments per 24 MFMAs; a 256 x 256 tile with 128 x 64 per wave moves 39 % fewer bytes per MAC
