@@ -34,3 +34,6 @@ def install_akgr_alias() -> None:
                      ("generation_expand_utils", generation_expand_utils), ("modeling_dream", modeling_dream)):
         sys.modules[f"{base}.{sub}"] = mod
         setattr(sys.modules[base], sub, mod)
+    from . import custom_gpt   # the legacy GPT-2 backbone lives one level up: akgr.abduction_model.model.custom_gpt
+    sys.modules[f"{chain[2]}.custom_gpt"] = custom_gpt
+    setattr(sys.modules[chain[2]], "custom_gpt", custom_gpt)

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv
                                                    const float* __restrict__ sinT,
                                                    const int32_t* __restrict__ pos,
                                                    const uint8_t* __restrict__ kmask, T* __restrict__ out,
-                                                   int N, int H, int max_pos, float scale) {
+                                                   int N, int H, int max_pos, float scale, int causal) {
   constexpr int VEC = AttnVec<T>::VEC;
   typedef typename AttnVec<T>::raw_t raw_t;
   constexpr int NP = NT * 16;     // padded token count
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float s = S[jt][r] * scale + kbias[jt * 16 + 4 * g + r];
+        float s = S[jt][r] * scale + kbias[jt * 16 + 4 * g + r];
+        if (causal && jt * 16 + 4 * g + r > qi) s = -INFINITY;  // (GPT-2 backbone only; wave-uniform flag)
         S[jt][r] = s;
         mx = fmaxf(mx, s);
       }
@@ -233,21 +234,21 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv
 
 template <typename T, int HD, int NT, int NW>
 static int launch_attn_t(const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
-                         const uint8_t* kmask, void* out, int B, int N, int H, int max_pos, hipStream_t st) {
+                         const uint8_t* kmask, void* out, int B, int N, int H, int max_pos, hipStream_t st, int causal) {
   constexpr int VEC = AttnVec<T>::VEC;
   constexpr int smem = 3 * NT * 16 * (HD + VEC) * (int)sizeof(T) + NT * 16 * 4;
   static SmemOptIn optin;
   DARK_TRY(optin.ensure((const void*)attn_kernel<T, HD, NT, NW>, smem, st));
   const float scale = 1.0f / sqrtf((float)HD);
   hipLaunchKernelGGL((attn_kernel<T, HD, NT, NW>), dim3(B * H), dim3(NW * 64), smem, st, (const T*)qkv, cosT, sinT, pos,
-                     kmask, (T*)out, N, H, max_pos, scale);
+                     kmask, (T*)out, N, H, max_pos, scale, causal);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }
 
 int launch_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                      const uint8_t* kmask, void* out, int B, int N, int H, int HD, int max_pos,
-                     hipStream_t st) {
+                     hipStream_t st, bool causal) {
   DARK_CHECK_ARG(N >= 1 && N <= 128, "attention: N=%d must be in [1,128]", N);
   DARK_CHECK_ARG(HD == 64 || HD == 96, "attention: head_dim=%d must be 64 or 96", HD);
   DARK_CHECK_ARG(max_pos >= 1, "attention: empty RoPE table");
@@ -255,9 +256,9 @@ int launch_attention(int dtype, const void* qkv, const float* cosT, const float*
   // per CU; 38.9 vs 42.0 us at B = 512 against the 4-tile / 4-wave instance), 4 (N <= 64) or 8 (N <= 128, two query
   // tiles per wave)
 #define DARK_ATTN(T, HDv)                                                                                        \
-  if (N <= 48) return launch_attn_t<T, HDv, 3, 3>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st);        \
-  if (N <= 64) return launch_attn_t<T, HDv, 4, 4>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st);        \
-  return launch_attn_t<T, HDv, 8, 4>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st)
+  if (N <= 48) return launch_attn_t<T, HDv, 3, 3>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0);        \
+  if (N <= 64) return launch_attn_t<T, HDv, 4, 4>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0);        \
+  return launch_attn_t<T, HDv, 8, 4>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0)
   if (dtype == DARK_BF16) {
     if (HD == 96) { DARK_ATTN(bf16_t, 96); } else { DARK_ATTN(bf16_t, 64); }
   } else {

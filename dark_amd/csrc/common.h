@@ -132,13 +132,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // ---- launchers implemented across the .hip files --------------------------
 // GEMM epilogues: C[M,N] = A[M,K] * W[N,K]^T (+...)
-enum Epi { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_F32 = 3, EPI_LSE = 4, EPI_HEAD = 5 };
+enum Epi { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_F32 = 3, EPI_LSE = 4, EPI_HEAD = 5, EPI_BIAS_GELU = 6,
+           EPI_RESID_BIAS = 7 };
 
 // A: [M,K] dtype, W: [Npad,K] dtype (rows padded to a multiple of 128 with zeros).
 // EPI_BIAS  : out (dtype) [M,ldo] = acc + bias[n]
 // EPI_RESID : resid (fp32) [M,ldo] += acc
 // EPI_SWIGLU: W rows interleaved in groups of 32 (gate|up); out (dtype) [M,ldo], ldo cols = N/2
 // EPI_F32   : out (fp32) [M,ldo] = acc, columns n < N only
+// EPI_BIAS_GELU : out (dtype) [M,ldo] = gelu_new(acc + bias[n])            (GPT-2 backbone: mlp.c_fc + act)
+// EPI_RESID_BIAS: resid (fp32) [M,ldo] += acc + bias[n]                     (GPT-2 backbone: attn / mlp c_proj)
 // EPI_LSE   : bf16 only; bias = int64 targets [M]; out = float2 part[M][ldo] (max, sum exp(acc - max)) per
 //             64-column wave slice, ldo = 2*ceil(N/128), followed by float tgt[M] = acc[m][target[m]]
 int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out,
@@ -191,7 +194,10 @@ int launch_gather_rows(int dtype, const void* att, void* att_out, const float* x
                        int n_src, int R, int d, hipStream_t st);
 int launch_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                      const uint8_t* kmask, void* out, int B, int N, int H, int HD, int max_pos,
-                     hipStream_t st);
+                     hipStream_t st, bool causal = false);
+// gpt2.hip: torch.nn.LayerNorm over gathered rows (src_rows nullable = identity, clamped to [0, n_src))
+int launch_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, const int32_t* src_rows,
+                     int n_src, int M, int d, float eps, hipStream_t st);
 int launch_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* row_index,
                      int32_t* src_rows, int32_t* count, hipStream_t st);
 int launch_sample(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p,

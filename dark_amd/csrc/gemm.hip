@@ -29,6 +29,13 @@ __device__ __forceinline__ float silu_fast(float g) {
   return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896340736f));
 }
 
+// GPT-2 backbone (custom_gpt.py:25-114 -> transformers' GPT2MLP): NewGELUActivation
+__device__ __forceinline__ float gelu_new_f(float x) {
+  return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+constexpr bool epi_has_bias(int epi) { return epi == EPI_BIAS || epi == EPI_BIAS_GELU; }
+constexpr bool epi_is_resid(int epi) { return epi == EPI_RESID || epi == EPI_RESID_BIAS; }
+
 // acc[mi][ni][r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 inside a 32x32 tile
 template <int EPI, typename T>
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const float* __restrict__ bias,
@@ -55,9 +62,14 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const float*
           const float v = acc[mi][ni][r];
           if constexpr (EPI == EPI_BIAS) {
             ((T*)out)[(int64_t)m * ldo + n] = ElemTraits<T>::from_f32(v + bias[n]);
+          } else if constexpr (EPI == EPI_BIAS_GELU) {
+            ((T*)out)[(int64_t)m * ldo + n] = ElemTraits<T>::from_f32(gelu_new_f(v + bias[n]));
           } else if constexpr (EPI == EPI_RESID) {
             float* p = (float*)out + (int64_t)m * ldo + n;
             *p = *p + v;
+          } else if constexpr (EPI == EPI_RESID_BIAS) {
+            float* p = (float*)out + (int64_t)m * ldo + n;
+            *p = *p + (v + bias[n]);
           } else {
             ((float*)out)[(int64_t)m * ldo + n] = v;
           }
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
     // latency per stage instead of one in front of every group of 8 MFMAs (+4 % on qkv and gate/up).  The residual
     // flavour keeps the compiler's interleaved order: with its prefetched residual pieces the 80 fragment registers
     // would spill.
-    if constexpr (EPI == EPI_RESID) {
+    if constexpr (epi_is_resid(EPI)) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int ch = ((4 * ks + fq) ^ fsw) << 4;
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
   auto resid_ok = [&](int mi, int ni) {
     return m0 + wm * 64 + mi * 16 + frow < M && n0 + wn * WN + 4 * fq + ni * 16 + 4 <= N;
   };
-  if constexpr (EPI == EPI_RESID) {
+  if constexpr (epi_is_resid(EPI)) {
     if (vec_ok) {
       ob = (float*)out + (int64_t)(m0 + wm * 64 + frow) * ldo + n0 + wn * WN + 4 * fq;
 #pragma unroll
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
   // Bias flavour: the TNW bias pieces of this lane's columns are fetched here, once, and ride under the first
   // stage's wait; in the epilogue they would be a dependent load in front of every store (24 a lane).
   float4 b4[TNW];
-  if constexpr (EPI == EPI_BIAS) {
+  if constexpr (epi_has_bias(EPI) || EPI == EPI_RESID_BIAS) {
 #pragma unroll
     for (int ni = 0; ni < TNW; ++ni) {
       const int c = n0 + wn * WN + ni * 16 + 4 * fq;
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < KT) stage((kt + 1) & 1, kt + 1);
-    if constexpr (EPI == EPI_RESID) {
+    if constexpr (epi_is_resid(EPI)) {
       if (vec_ok && kt == KT - 1) {  // the other two row groups ride under the last compute step
 #pragma unroll
         for (int mi = 2; mi < 4; ++mi)
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
   }
 
   // Residual flavour, 16-byte path: second half of the read-modify-write (see the prefetch above the main loop).
-  if constexpr (EPI == EPI_RESID) {
+  if constexpr (epi_is_resid(EPI)) {
     if (vec_ok) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -291,8 +303,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
         for (int ni = 0; ni < TNW; ++ni)
           if (resid_ok(mi, ni)) {
             const float4 p = mi < 2 ? old0[mi & 1][ni] : old1[mi & 1][ni];
-            *(float4*)(ob + (int64_t)mi * 16 * ldo + ni * 16) =
-                make_float4(acc[ni][mi][0] + p.x, acc[ni][mi][1] + p.y, acc[ni][mi][2] + p.z, acc[ni][mi][3] + p.w);
+            f32x4 a = acc[ni][mi];
+            if constexpr (EPI == EPI_RESID_BIAS) {  // hidden + (acc + bias): the order of c_proj's addmm, then the residual add
+              a[0] += b4[ni].x; a[1] += b4[ni].y; a[2] += b4[ni].z; a[3] += b4[ni].w;
+            }
+            *(float4*)(ob + (int64_t)mi * 16 * ldo + ni * 16) = make_float4(a[0] + p.x, a[1] + p.y, a[2] + p.z, a[3] + p.w);
           }
     }
   }
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
             if (c + e < nout) orow[c + e] = (bf16_t)v[TO - 1][e];
         }
       }
-    } else if constexpr (EPI == EPI_BIAS) {
+    } else if constexpr (epi_has_bias(EPI)) {
 #pragma unroll
       for (int np = 0; np < TNW / 2; ++np) {
         float v[2][4];
@@ -335,6 +350,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
           const int ni = 2 * np + t;
           v[t][0] = acc[ni][mi][0] + b4[ni].x; v[t][1] = acc[ni][mi][1] + b4[ni].y;
           v[t][2] = acc[ni][mi][2] + b4[ni].z; v[t][3] = acc[ni][mi][3] + b4[ni].w;
+          if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[t][e] = gelu_new_f(v[t][e]);
+          }
         }
         store_pair_bf16(v[0], v[1], (bf16_t*)out + mrow * ldo, n0 + wn * WN + np * 32, row_ok ? N : 0, fq, vec_ok);
       }
@@ -375,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
       }
     } else {
       if (!row_ok) continue;
-      if constexpr (EPI == EPI_RESID) {
+      if constexpr (epi_is_resid(EPI)) {
         if (vec_ok) continue;  // done above, in batches
       }
       float* orow = (float*)out + mrow * ldo;
@@ -389,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
           for (int e = 0; e < 4; ++e) {
             if (c + e >= N) continue;
             if constexpr (EPI == EPI_RESID) orow[c + e] += acc[ni][mi][e];
+            else if constexpr (EPI == EPI_RESID_BIAS) orow[c + e] += acc[ni][mi][e] + bias[c + e];
             else orow[c + e] = acc[ni][mi][e];
           }
         }
@@ -501,7 +521,7 @@ static int launch_epi(int dtype, const void* A, const void* W, const float* bias
   const int nwg = tilesM * tilesN;
   if (dtype == DARK_BF16) {
     // 16-B row pieces need 16-B aligned rows: bf16 outputs 8 elements, fp32 outputs 4
-    const int per16 = (EPI == EPI_BIAS || EPI == EPI_SWIGLU) ? 8 : 4;
+    const int per16 = (epi_has_bias(EPI) || EPI == EPI_SWIGLU) ? 8 : 4;
     const int ncols = EPI == EPI_SWIGLU ? N / 2 : N;
     const int vec_ok = (ldo % per16 == 0) && (ncols % per16 == 0) &&
                        ((uintptr_t)out % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
@@ -628,6 +648,12 @@ static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, co
       DARK_CHECK_ARG(bias != nullptr, "gemm: EPI_BIAS needs a bias");
       return launch_epi<EPI_BIAS>(dtype, A, W, bias, out, M, N, K, ldo, st);
     case EPI_RESID: return launch_epi<EPI_RESID>(dtype, A, W, bias, out, M, N, K, ldo, st);
+    case EPI_BIAS_GELU:
+      DARK_CHECK_ARG(bias != nullptr, "gemm: EPI_BIAS_GELU needs a bias");
+      return launch_epi<EPI_BIAS_GELU>(dtype, A, W, bias, out, M, N, K, ldo, st);
+    case EPI_RESID_BIAS:
+      DARK_CHECK_ARG(bias != nullptr, "gemm: EPI_RESID_BIAS needs a bias");
+      return launch_epi<EPI_RESID_BIAS>(dtype, A, W, bias, out, M, N, K, ldo, st);
     case EPI_SWIGLU:
       DARK_CHECK_ARG(N % 32 == 0, "gemm: SWIGLU needs N %% 32 == 0 (N=%d)", N);
       return launch_epi<EPI_SWIGLU>(dtype, A, W, bias, out, M, N, K, ldo, st);

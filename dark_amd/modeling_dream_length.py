@@ -131,7 +131,7 @@ class HipState:
         self.pk, self.cfg, self.B, self.N = packed, cfg, B, N
         dev = packed.device
         rows = B * N
-        self.fwd_bytes = self.lib.dark_forward_workspace_bytes(packed.ref, B, N)
+        self.fwd_bytes = self._workspace_bytes(B, N)
         self.fwd_ws = torch.empty(self.fwd_bytes, dtype=torch.uint8, device=dev)
         self.hidden = torch.empty((rows, cfg.hidden_size), dtype=torch.float32, device=dev)
         self.row_index = torch.zeros(rows, dtype=torch.int32, device=dev)
@@ -159,6 +159,9 @@ class HipState:
 
     def _s(self) -> int:
         return _hip.stream_ptr(self.pk.device)
+
+    def _workspace_bytes(self, B: int, N: int) -> int:
+        return self.lib.dark_forward_workspace_bytes(self.pk.ref, B, N)
 
     def _ensure_head(self, M: int) -> None:
         if self.head_ws is None or self.head_ws.numel() < M * self.cfg.hidden_size * self.pk.elem + 256:

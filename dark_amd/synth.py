@@ -138,3 +138,57 @@ def boost_edit_tokens(weights: Dict[str, torch.Tensor], expand_gain: float = 0.0
         head[delete_id] = unit * typical * delete_gain
     w["lm_head.weight"] = head
     return w
+
+
+# ---- GPT-2 backbone (akgr/abduction_model/model/custom_gpt.py)
+def gpt2_state_dict_layout(cfg) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Names/shapes of transformers' ``GPT2LMHeadModel.state_dict()`` (Conv1D weights are [in, out]); ``lm_head.weight``
+    is tied to ``transformer.wte.weight`` and not listed."""
+    d, inner = cfg.n_embd, (getattr(cfg, "n_inner", None) or 4 * cfg.n_embd)
+    names: List[Tuple[str, Tuple[int, ...]]] = [("transformer.wte.weight", (cfg.vocab_size, d)),
+                                                ("transformer.wpe.weight", (cfg.n_positions, d))]
+    for i in range(cfg.n_layer):
+        p = f"transformer.h.{i}."
+        names += [(p + "ln_1.weight", (d,)), (p + "ln_1.bias", (d,)),
+                  (p + "attn.c_attn.weight", (d, 3 * d)), (p + "attn.c_attn.bias", (3 * d,)),
+                  (p + "attn.c_proj.weight", (d, d)), (p + "attn.c_proj.bias", (d,)),
+                  (p + "ln_2.weight", (d,)), (p + "ln_2.bias", (d,)),
+                  (p + "mlp.c_fc.weight", (d, inner)), (p + "mlp.c_fc.bias", (inner,)),
+                  (p + "mlp.c_proj.weight", (inner, d)), (p + "mlp.c_proj.bias", (d,))]
+    names += [("transformer.ln_f.weight", (d,)), ("transformer.ln_f.bias", (d,))]
+    return names
+
+
+def make_gpt2_weights(cfg, seed: int = 0, rich: bool = False, std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """fp32 CPU state_dict with GPT2PreTrainedModel._init_weights' distribution (normal(0, 0.02), zero biases, unit
+    LayerNorm weights); ``rich=True`` randomises biases and LayerNorm parameters so parity tests exercise them."""
+    g = torch.Generator().manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in gpt2_state_dict_layout(cfg):
+        if ".ln_" in name:
+            t = torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
+            if rich:
+                t = t + 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith(".bias"):
+            t = torch.randn(shape, generator=g) * std if rich else torch.zeros(shape)
+        else:
+            t = torch.randn(shape, generator=g) * std
+        out[name] = t
+    out["lm_head.weight"] = out["transformer.wte.weight"]
+    return out
+
+
+def boost_gpt2_edit_tokens(weights: Dict[str, torch.Tensor], expand_gain: float = 0.0, delete_gain: float = 0.0,
+                           mask_id: int = MASK, expand_id: int = EXPAND, delete_id: int = END
+                           ) -> Dict[str, torch.Tensor]:
+    """boost_edit_tokens for the tied head: the wte rows of EXPAND / DELETE are pointed along the MASK embedding."""
+    w = dict(weights)
+    wte = w["transformer.wte.weight"].clone()
+    unit = wte[mask_id] / wte[mask_id].norm()
+    typical = wte.norm(dim=1).median()
+    if expand_gain:
+        wte[expand_id] = unit * typical * expand_gain
+    if delete_gain:
+        wte[delete_id] = unit * typical * delete_gain
+    w["transformer.wte.weight"] = w["lm_head.weight"] = wte
+    return w

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DARK_HIP_ABI_VERSION 3
+#define DARK_HIP_ABI_VERSION 4
 
 #define DARK_OK 0
 #define DARK_ERR_ARG 1         /* bad shape / pointer / unsupported size */
@@ -338,12 +338,70 @@ int dark_prof_select_gemm(int epi);
 int dark_prof_select_gemm_rows(int epi, int rows);
 int dark_prof_read(double* total_ms, double* total_flops, int* launches);
 
+/* ---- GPT-2 backbone of the legacy denoiser: akgr/abduction_model/model/custom_gpt.py:25-114,
+ * `DiffusionModel(GPT2LMHeadModel)` built by create_gpt2_transformer (:446-472).  Weights are packed by
+ * dark_amd/custom_gpt.py from the HF GPT-2 state_dict: Conv1D weights ([in, out]) are stored TRANSPOSED here, i.e.
+ * row-major [out_features_padded, in_features] in the model dtype like every other weight of this library. */
+typedef struct dark_gpt2_layer_weights {
+  const void* w_qkv;    /* [3d, d]  = attn.c_attn.weight^T (q rows, k rows, v rows)  */
+  const float* b_qkv;   /* [3d]                                                      */
+  const void* w_o;      /* [d, d]   = attn.c_proj.weight^T                           */
+  const float* b_o;     /* [d]                                                       */
+  const void* w_fc;     /* [ff, d]  = mlp.c_fc.weight^T                              */
+  const float* b_fc;    /* [ff]                                                      */
+  const void* w_proj;   /* [d, ff]  = mlp.c_proj.weight^T                            */
+  const float* b_proj;  /* [d]                                                       */
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b; /* ln_1 / ln_2 weight and bias [d] fp32 */
+} dark_gpt2_layer_weights;
+
+typedef struct dark_gpt2_desc {
+  int32_t dtype;        /* DARK_F32 | DARK_BF16 */
+  int32_t vocab;
+  int32_t vocab_pad;    /* rows of wte, multiple of 128 */
+  int32_t d;            /* n_embd, multiple of 64 */
+  int32_t ff;           /* n_inner (4 * n_embd), multiple of 64 */
+  int32_t n_layers;
+  int32_t n_heads;
+  int32_t head_dim;     /* 64 or 96 */
+  int32_t n_positions;  /* rows of wpe */
+  float ln_eps;         /* layer_norm_epsilon */
+  const void* wte;      /* [vocab_pad, d] model dtype: token embedding AND the tied LM head (transformer.wte) */
+  const void* wpe;      /* [n_positions, d] model dtype (transformer.wpe) */
+  const float* lnf_w;   /* transformer.ln_f weight / bias [d] fp32 */
+  const float* lnf_b;
+  const float* ident_cos; /* [head_dim/2] fp32, all 1: one-row rotation table for the shared attention kernel */
+  const float* ident_sin; /* [head_dim/2] fp32, all 0 */
+  const dark_gpt2_layer_weights* layers; /* HOST array of n_layers entries */
+} dark_gpt2_desc;
+
+/* Body of DiffusionModel.forward (custom_gpt.py:58-100 -> transformers' GPT2Model): wte[ids] + wpe[pos], L x [LayerNorm,
+ * c_attn + bias, attention (1/sqrt(head_dim) scaling, key padding mask), c_proj + bias + residual, LayerNorm, c_fc +
+ * bias + GELU-new, c_proj + bias + residual]; ln_f is applied by dark_gpt2_lm_head_rows.
+ *   pos      [B,N] int32 position ids (custom_gpt.py:352-353: cumsum(attention_mask) - 1, padding -> 1) or NULL = arange
+ *   key_mask [B,N] uint8 (1 = attend) or NULL: the [B, N] attention_mask of :344-346 (keys only; rows whose own entry
+ *            is 0 come out as zeros here -- the reference never reads them: mask_index requires attention_mask == 1)
+ *   causal   0 = bidirectional (what the class intends, :34-36), 1 = causal (what transformers' sdpa path computes
+ *            whatever the `attn.bias` buffer holds); see gpt2.hip
+ *   hidden   [B*N, d] fp32 OUT (pre ln_f).  Workspace: dark_gpt2_forward_workspace_bytes(m, B, N). */
+size_t dark_gpt2_forward_workspace_bytes(const dark_gpt2_desc* m, int B, int N);
+int dark_gpt2_forward_hidden(const dark_gpt2_desc* m, const int64_t* ids, const int32_t* pos, const uint8_t* key_mask,
+                             int causal, int B, int N, void* workspace, size_t workspace_bytes, float* hidden,
+                             void* stream);
+/* ln_f + the tied LM head (custom_gpt.py:100-103) on selected rows; arguments as dark_lm_head_rows, workspace
+ * >= M * d * sizeof(model dtype) rounded up to 256. */
+int dark_gpt2_lm_head_rows(const dark_gpt2_desc* m, const float* hidden, const int32_t* src_rows, int M, void* workspace,
+                           size_t workspace_bytes, float* logits, int64_t ldl, void* stream);
+/* test hook: torch.nn.LayerNorm over (gathered) fp32 rows -> model dtype */
+int dark_dbg_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, const int32_t* src_rows,
+                       int n_src, int M, int d, float eps, void* stream);
+
 /* ---- unit-test hooks (no counterpart in the reference): launch ONE kernel of the path so that
  * tests/test_hip_kernels.py can pin it against the oracle in isolation.
  *   epi: 0 = +bias (out in model dtype), 1 = residual add into fp32 out, 2 = SwiGLU over interleaved
  *        gate/up rows, groups of 16 (bf16) / 32 (fp32) (out [M, N/2] model dtype), 3 = plain fp32 store,
  *        4 = bf16 only, log-sum-exp partials: bias = int64 targets [M], out = float2 [M, ldo = 2*ceil(N/128)] then
- *        float [M] target logits.  W has rows padded to 128. */
+ *        float [M] target logits; 6 = gelu_new(acc + bias) (out in model dtype), 7 = residual add of acc + bias into
+ *        fp32 out (the GPT-2 backbone's c_fc / c_proj).  W has rows padded to 128. */
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                   int N, int K, int64_t ldo, void* stream);
 /* LM head + sampler for the M masked rows in one call, without materialising the logits where that is possible.
