@@ -605,9 +605,13 @@ int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* b
 static std::atomic<int> g_gemm_variant{0};
 int gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 void set_p256_nodma(int v);
-void set_gemm_variant(int v) {  // 3 = timing probe: variant 2 with the main loop's LDS-DMA issue removed (wrong results)
+void set_s256_probe(int v);
+// 3 = timing probe: variant 2 with the main loop's LDS-DMA issue removed (wrong results); 16 + p = timing probe p of
+// gemm_bf16_s256 (gemm256.hip, wrong results): variant 4 with parts of its intervals removed
+void set_gemm_variant(int v) {
   set_p256_nodma(v == 3);
-  g_gemm_variant.store(v == 3 ? 2 : v, std::memory_order_relaxed);
+  set_s256_probe(v >= 16 ? v - 16 : 0);
+  g_gemm_variant.store(v == 3 ? 2 : (v >= 16 ? 4 : v), std::memory_order_relaxed);
 }
 
 // Which kernel serves a bf16 GEMM: 0 = the 128-row kernels of this file, 2 = gemm_bf16_p256, 4 = gemm_bf16_s256.

@@ -263,10 +263,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256(const bf16_t* __restrict__
 // Output goes through buffer stores: rows >= M and columns >= N fall outside the descriptor and are dropped by the
 // hardware, so every wave issues the same number of stores per tile and the counted `vmcnt` waits stay exact.
 namespace {
-constexpr int SBK = 32, S_NBUF = 4;
+constexpr int SBK = 32;
+// K-tiles live in LDS.  Five (all 160 KiB) for every flavour but the bias one, which keeps its bias vector behind four:
+// per-phase timestamps (tools/probe/gemm_s256_probe.py) showed ~90 cycles per interval of EXPOSED wait for the DMA
+// issued three K-tiles (~1500 cycles) earlier -- L2 / Infinity-Cache latency under a load of 256 CUs x 40 GB/s -- on
+// the LOAD side, which is the critical side of every interval; a fifth buffer lets the DMA run four K-tiles ahead.
+constexpr int s_nbuf(int epi) { return epi == EPI_BIAS ? 4 : 5; }
 constexpr int S_OPER = 256 * SBK * 2;   // 16 KiB per operand K-tile
 constexpr int S_BUF = 2 * S_OPER;       // 32 KiB per K-tile
-constexpr int S_SMEM = S_NBUF * S_BUF;  // 128 KiB
+constexpr int s_smem(int epi) { return s_nbuf(epi) * S_BUF; }  // 160 KiB (128 KiB + bias for EPI_BIAS)
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int EPI> struct StoresPerTile;                                   // buffer stores a wave issues per tile
 template <> struct StoresPerTile<EPI_SWIGLU> { static constexpr int N = 8; };
@@ -276,7 +281,12 @@ template <> struct StoresPerTile<EPI_HEAD> { static constexpr int N = 8; };
 constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }  // vmcnt(n), nothing else
 }  // namespace
 
-template <int EPI>
+// PROBE != 0: timing-only builds (WRONG RESULTS) that tell where an interval's time goes -- bit 0: no LDS-DMA issue in
+// the steady state, bit 1: no fragment reads after the first K-tile, bit 2: no epilogue arithmetic / stores; bit 3
+// (results stay correct): per-wave cycle sums of the interval's phases, written through `bias` as int64[grid][8 waves][6]
+// = {LOAD work until its reads have returned, wait for the next K-tile's DMA, barrier wait behind LOAD, MFMA issue,
+// barrier wait behind the MFMAs, K-tiles} (s_memtime costs a few dozen cycles per sample: proportions, not absolutes).
+template <int EPI, int PROBE = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ bias, void* __restrict__ out, int M,
                                                       int N, int K, int64_t ldo, int tilesM, int tilesN, int ntiles,
@@ -284,6 +294,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
                                                       const int* __restrict__ m_dev, float hp_c2, float hp_range) {
   constexpr int GM = 8;
   constexpr int NST = StoresPerTile<EPI>::N;
+  constexpr int NB = s_nbuf(EPI);          // LDS buffers; the DMA runs NB - 1 K-tiles ahead of the reads
+  constexpr int AHEAD_OPS = 4 * (NB - 2);  // DMAs of this wave that are younger than the NEXT K-tile's batch
+  constexpr int S_SMEM = NB * S_BUF;
   if (m_dev) {  // row count from device memory (never more than the host's M, which sized the buffers)
     const int md = __builtin_amdgcn_readfirstlane(*m_dev);
     M = md < M ? (md > 0 ? md : 0) : M;
@@ -309,7 +322,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int p = wave * 2 + q;
-      const unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
+      unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
+      if constexpr (PROBE & 16) {
+        // timing probe (WRONG results): the same bytes over two K-tiles, fetched as WHOLE 128-byte lines -- 8 rows x
+        // 128 B per instruction, rows [0,128) on even K-tiles and [128,256) on odd ones -- instead of two 64-byte halves
+        // of every line one K-tile apart
+        so = (unsigned)(p * 8 + (kt & 1) * 128) * kb + (unsigned)(kt >> 1) * 128u +
+             ((unsigned)(lane >> 3) * kb + (unsigned)(lane & 7) * 16u) - voff;
+      }
       // (the whole offset goes into the VGPR operand: the SGPR offset is EXCLUDED from the descriptor's bounds check)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + p * 1024), 16, voff + (a0 + so), 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + S_OPER + p * 1024), 16, voff + (w0 + so), 0, 0, 0);
@@ -340,12 +360,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
     d_a0 = (unsigned)tm * 256u * kb;
     d_w0 = (unsigned)tn * 256u * kb;
   }
+  bool probe_warm = false;  // (PROBE builds: set once the pipeline is primed)
   auto stage_next = [&]() {
+    if constexpr (PROBE & 1) { if (probe_warm) return; }
     if (d_id < ntiles) stage(d_buf, d_a0, d_w0, d_kt);
     else {  // past the last tile: keep the per-phase DMA count constant (the counted waits rely on it)
       stage(d_buf, 0xF0000000u, 0xF0000000u, 0);  // out of range: nothing is fetched, zeros land in a dead buffer
     }
-    d_buf = (d_buf + 1) & (S_NBUF - 1);
+    d_buf = d_buf + 1 == NB ? 0 : d_buf + 1;
     if (++d_kt == KT) {
       d_kt = 0;
       d_id += G;
@@ -357,10 +379,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
       }
     }
   };
-  stage_next();
-  stage_next();
-  stage_next();
-  __builtin_amdgcn_s_waitcnt(waitcnt_vm(8));  // K-tile 0 has landed (this wave's pieces)
+#pragma unroll
+  for (int i = 0; i < NB - 1; ++i) stage_next();
+  probe_warm = true;
+  __builtin_amdgcn_s_waitcnt(waitcnt_vm(AHEAD_OPS));  // K-tile 0 has landed (this wave's pieces)
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one interval behind group 0
 
@@ -371,6 +393,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   // epilogue of the tile at (m0, n0): this lane owns row (lane & 15) of each 16-row tile, 4 consecutive columns of
   // each 16-column tile; exactly NST buffer stores per wave (out-of-range ones are dropped by the descriptor)
   auto epilogue = [&](int m0, int n0) {
+    if constexpr (PROBE & 4) {  // keep the accumulators alive with one never-taken store
+      float sacc = 0.f;
+#pragma unroll
+      for (int j = 0; j < P_NI; ++j)
+#pragma unroll
+        for (int i = 0; i < P_MI; ++i) sacc += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+      if (sacc == 12345.678f) __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){0u, 0u, 0u, 0u}, ro, 0u, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int mi = 0; mi < P_MI; ++mi) {
       const int m = m0 + grp * 128 + mi * 16 + frow;
@@ -479,13 +510,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
 
   int pm0 = 0, pn0 = 0;   // the tile whose accumulators are waiting for their epilogue
   bool pending = false;
+  long long pt[6] = {0, 0, 0, 0, 0, 0};
+  auto now = [&]() -> long long {
+    if constexpr (PROBE & 8) return (long long)__builtin_readcyclecounter();
+    else return 0;
+  };
   for (int id = wg; id < ntiles; id += G) {
     int tm, tn;
     tile_of(id, tm, tn);
     for (int kt = 0; kt < KT; ++kt) {
       // ================= LOAD interval =================
+      const long long t0 = now();
       if (kt == 0 && pending) epilogue(pm0, pn0);   // the partner group's MFMAs run meanwhile
-      {
+      if (!(PROBE & 2) || (!pending && kt == 0)) {
         const char* as = smem + rbuf * S_BUF + a_rd;
         const char* ws = smem + rbuf * S_BUF + w_rd;
 #pragma unroll
@@ -494,14 +531,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         for (int i = 0; i < P_MI; ++i) fa[i] = *(const bf16x8*)(as + i * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
-      stage_next();  // K-tile three phases ahead, into the buffer both groups finished reading one interval ago
+      stage_next();  // K-tile NB - 1 phases ahead, into the buffer both groups finished reading one interval ago
       __builtin_amdgcn_sched_barrier(0);
-      // this wave's pieces of the NEXT K-tile have landed: its batch is followed by two younger batches (8 DMAs)
-      // and, for the two phases behind an epilogue, by that epilogue's NST stores
-      if (pending && kt < 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(8 + NST) & 0xF0FF);  // + lgkmcnt(0)
-      else __builtin_amdgcn_s_waitcnt(waitcnt_vm(8) & 0xF0FF);
+      // this wave's pieces of the NEXT K-tile have landed: its batch is followed by NB - 2 younger batches (4 DMAs
+      // each) and, for the NB - 2 phases behind an epilogue, by that epilogue's NST stores (the batch of K-tile kt + 1
+      // was issued NB - 2 intervals before this one; the stores at kt = 0, in front of that interval's batch)
+      long long t1 = 0, t2 = 0;
+      if constexpr (PROBE & 8) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: the fragment reads have returned
+        t1 = now();
+      }
+      if (pending && kt < NB - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(AHEAD_OPS + NST) & 0xF0FF);  // + lgkmcnt(0)
+      else __builtin_amdgcn_s_waitcnt(waitcnt_vm(AHEAD_OPS) & 0xF0FF);
+      if constexpr (PROBE & 8) t2 = now();
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      const long long t3 = now();
       // ================= MFMA interval =================
       if (kt == 0) {
 #pragma unroll
@@ -516,14 +561,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
           for (int i = 0; i < P_MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      const long long t4 = now();
       __builtin_amdgcn_s_barrier();
-      rbuf = (rbuf + 1) & (S_NBUF - 1);
+      if constexpr (PROBE & 8) {
+        const long long t5 = now();
+        pt[0] += t1 - t0; pt[1] += t2 - t1; pt[2] += t3 - t2; pt[3] += t4 - t3; pt[4] += t5 - t4; pt[5] += 1;
+      }
+      rbuf = rbuf + 1 == NB ? 0 : rbuf + 1;
     }
     pm0 = tm * 256;
     pn0 = tn * 256;
     pending = true;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's last interval
+  if constexpr (PROBE & 8) {
+    if (lane == 0 && bias) {
+      long long* o = (long long*)bias + ((size_t)blockIdx.x * 8 + wave) * 6;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) o[i] = pt[i];
+    }
+  }
   epilogue(pm0, pn0);
   __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
 }
@@ -584,9 +641,12 @@ bool s256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, c
   if (!p256_supports(epi, M, N, K, ldo, out, bias) || K < 128) return false;
   const int64_t es = epi == EPI_F32 ? 4 : 2;
   if (((int64_t)M + 256) * ldo * es >= 0xE0000000ll) return false;  // 32-bit byte offsets of the buffer stores
-  if (epi == EPI_BIAS && (cdiv(N, 256) * 256 * 4 > 160 * 1024 - S_SMEM || ((uintptr_t)bias & 3))) return false;
+  if (epi == EPI_BIAS && (cdiv(N, 256) * 256 * 4 > 160 * 1024 - s_smem(EPI_BIAS) || ((uintptr_t)bias & 3))) return false;
   return true;
 }
+
+static std::atomic<int> g_s256_probe{0};
+void set_s256_probe(int v) { g_s256_probe.store(v); }
 
 int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                      int64_t ldo, int w_rows, hipStream_t st) {
@@ -600,7 +660,7 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   const int64_t es = epi == EPI_F32 ? 4 : 2;
   const unsigned a_bytes = (unsigned)((int64_t)M * K * 2), w_bytes = (unsigned)((int64_t)w_rows * K * 2);
   const unsigned o_bytes = (unsigned)((int64_t)M * ldo * es);
-  const int smem = S_SMEM + (epi == EPI_BIAS ? tilesN * 256 * 4 : 0);
+  const int smem = s_smem(epi) + (epi == EPI_BIAS ? tilesN * 256 * 4 : 0);
 #define DARK_S256(E)                                                                                               \
   {                                                                                                                \
     static SmemOptIn optin;                                                                                        \
@@ -609,9 +669,27 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
                        bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes,                 \
                        (const int*)nullptr, 0.f, 0.f);                                                             \
   }
-  if (epi == EPI_SWIGLU) DARK_S256(EPI_SWIGLU)
+#define DARK_S256_PROBE(PB)                                                                                        \
+  {                                                                                                                \
+    static SmemOptIn optin;                                                                                        \
+    DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<EPI_SWIGLU, PB>, smem, st));                                 \
+    hipLaunchKernelGGL((gemm_bf16_s256<EPI_SWIGLU, PB>), dim3(grid), dim3(512), smem, st, (const bf16_t*)A,        \
+                       (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes, \
+                       (const int*)nullptr, 0.f, 0.f);                                                             \
+  }
+  const int probe = epi == EPI_SWIGLU ? g_s256_probe.load() : 0;
+  if (probe == 1) DARK_S256_PROBE(1)
+  else if (probe == 2) DARK_S256_PROBE(2)
+  else if (probe == 3) DARK_S256_PROBE(3)
+  else if (probe == 4) DARK_S256_PROBE(4)
+  else if (probe == 7) DARK_S256_PROBE(7)
+  else if (probe == 8) DARK_S256_PROBE(8)
+  else if (probe == 16) DARK_S256_PROBE(16)
+  else if (probe == 24) DARK_S256_PROBE(24)
+  else if (epi == EPI_SWIGLU) DARK_S256(EPI_SWIGLU)
   else if (epi == EPI_BIAS) DARK_S256(EPI_BIAS)
   else DARK_S256(EPI_F32)
+#undef DARK_S256_PROBE
 #undef DARK_S256
   DARK_CHECK_LAUNCH();
   return DARK_OK;
@@ -645,8 +723,8 @@ int launch_gemm_head(const void* A, const void* W, void* records, int M, int N, 
   const unsigned a_bytes = (unsigned)((int64_t)M * K * 2), w_bytes = (unsigned)((int64_t)w_rows * K * 2);
   const unsigned o_bytes = (unsigned)((int64_t)M * tilesN * 4 * 16);
   static SmemOptIn optin;
-  DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<EPI_HEAD>, S_SMEM, st));
-  hipLaunchKernelGGL((gemm_bf16_s256<EPI_HEAD>), dim3(grid), dim3(512), S_SMEM, st, (const bf16_t*)A, (const bf16_t*)W,
+  DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<EPI_HEAD>, s_smem(EPI_HEAD), st));
+  hipLaunchKernelGGL((gemm_bf16_s256<EPI_HEAD>), dim3(grid), dim3(512), s_smem(EPI_HEAD), st, (const bf16_t*)A, (const bf16_t*)W,
                      (const float*)nullptr, records, M, N, K, (int64_t)0, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes,
                      m_dev, c2, range);
   DARK_CHECK_LAUNCH();
@@ -665,8 +743,8 @@ int launch_gemm_s256_devrows(const void* A, const void* W, void* out, int M, int
   const unsigned a_bytes = (unsigned)((int64_t)M * K * 2), w_bytes = (unsigned)((int64_t)w_rows * K * 2);
   const unsigned o_bytes = (unsigned)((int64_t)M * ldo * 4);
   static SmemOptIn optin;
-  DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<EPI_F32>, S_SMEM, st));
-  hipLaunchKernelGGL((gemm_bf16_s256<EPI_F32>), dim3(grid), dim3(512), S_SMEM, st, (const bf16_t*)A, (const bf16_t*)W,
+  DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<EPI_F32>, s_smem(EPI_F32), st));
+  hipLaunchKernelGGL((gemm_bf16_s256<EPI_F32>), dim3(grid), dim3(512), s_smem(EPI_F32), st, (const bf16_t*)A, (const bf16_t*)W,
                      (const float*)nullptr, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes, m_dev, 0.f,
                      0.f);
   DARK_CHECK_LAUNCH();
