@@ -296,6 +296,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   constexpr int NST = StoresPerTile<EPI>::N;
   constexpr int NB = s_nbuf(EPI);          // LDS buffers; the DMA runs NB - 1 K-tiles ahead of the reads
   constexpr int AHEAD_OPS = 4 * (NB - 2);  // DMAs of this wave that are younger than the NEXT K-tile's batch
+  // Pieces of a K-tile's batch that a wave issues in its LOAD interval; the rest follow its MFMAs, in the time it would
+  // otherwise spend at the barrier waiting for the loading group (PROBE bits 5, 6 select 1 and 0: A/B builds).
+  constexpr int QL = (PROBE & 32) ? 1 : ((PROBE & 64) ? 0 : 2);
+  constexpr int WAIT_OPS = AHEAD_OPS - 2 * (2 - QL);  // ... of which 2 * (2 - QL) have not been issued yet at the wait
   constexpr int S_SMEM = NB * S_BUF;
   if (m_dev) {  // row count from device memory (never more than the host's M, which sized the buffers)
     const int md = __builtin_amdgcn_readfirstlane(*m_dev);
@@ -317,10 +321,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   const unsigned kb = (unsigned)K * 2u;
   // piece = 16 rows x 64 B: lane l -> row (l >> 2), position l & 3 holds logical chunk (l & 3) ^ ((l >> 4) & 2)
   const unsigned voff = (unsigned)(lane >> 2) * kb + (unsigned)(((lane & 3) ^ ((lane >> 4) & 2)) << 4);
-  auto stage = [&](int buf, unsigned a0, unsigned w0, int kt) {  // this wave's 2 + 2 pieces of K-tile kt
+  // this wave's pieces q0 .. q1-1 (of 2: one A and one W piece each) of K-tile kt
+  auto stage = [&](int buf, unsigned a0, unsigned w0, int kt, int q0 = 0, int q1 = 2) {
     char* base = smem + buf * S_BUF;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = q0; q < q1; ++q) {
       const int p = wave * 2 + q;
       unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
       if constexpr (PROBE & 16) {
@@ -361,12 +366,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
     d_w0 = (unsigned)tn * 256u * kb;
   }
   bool probe_warm = false;  // (PROBE builds: set once the pipeline is primed)
-  auto stage_next = [&]() {
+  // pieces [q0, q1) of the cursor's K-tile; the cursor moves on with the last piece
+  auto stage_next = [&](int q0 = 0, int q1 = 2) {
     if constexpr (PROBE & 1) { if (probe_warm) return; }
-    if (d_id < ntiles) stage(d_buf, d_a0, d_w0, d_kt);
+    if (d_id < ntiles) stage(d_buf, d_a0, d_w0, d_kt, q0, q1);
     else {  // past the last tile: keep the per-phase DMA count constant (the counted waits rely on it)
-      stage(d_buf, 0xF0000000u, 0xF0000000u, 0);  // out of range: nothing is fetched, zeros land in a dead buffer
+      stage(d_buf, 0xF0000000u, 0xF0000000u, 0, q0, q1);  // out of range: nothing is fetched, zeros land in a dead buffer
     }
+    if (q1 < 2) return;
     d_buf = d_buf + 1 == NB ? 0 : d_buf + 1;
     if (++d_kt == KT) {
       d_kt = 0;
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         for (int i = 0; i < P_MI; ++i) fa[i] = *(const bf16x8*)(as + i * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
-      stage_next();  // K-tile NB - 1 phases ahead, into the buffer both groups finished reading one interval ago
+      if constexpr (QL > 0) stage_next(0, QL);  // K-tile NB - 1 phases ahead, into the buffer both groups finished reading one interval ago
       __builtin_amdgcn_sched_barrier(0);
       // this wave's pieces of the NEXT K-tile have landed: its batch is followed by NB - 2 younger batches (4 DMAs
       // each) and, for the NB - 2 phases behind an epilogue, by that epilogue's NST stores (the batch of K-tile kt + 1
@@ -541,14 +548,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: the fragment reads have returned
         t1 = now();
       }
-      if (pending && kt < NB - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(AHEAD_OPS + NST) & 0xF0FF);  // + lgkmcnt(0)
-      else __builtin_amdgcn_s_waitcnt(waitcnt_vm(AHEAD_OPS) & 0xF0FF);
+      if (pending && kt < NB - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(WAIT_OPS + NST) & 0xF0FF);  // + lgkmcnt(0)
+      else __builtin_amdgcn_s_waitcnt(waitcnt_vm(WAIT_OPS) & 0xF0FF);
       if constexpr (PROBE & 8) t2 = now();
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       const long long t3 = now();
       // ================= MFMA interval =================
-      if (kt == 0) {
+      if constexpr (PROBE & 128) {  // timing probe: data movement only (one MFMA keeps the fragments alive)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kt & 3], fa[kt & 7], kt ? acc[0][0] : (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      } else if (kt == 0) {
 #pragma unroll
         for (int j = 0; j < P_NI; ++j)
 #pragma unroll
@@ -560,6 +569,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
 #pragma unroll
           for (int i = 0; i < P_MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (QL < 2) stage_next(QL, 2);
       __builtin_amdgcn_sched_barrier(0);
       const long long t4 = now();
       __builtin_amdgcn_s_barrier();
@@ -686,6 +697,12 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   else if (probe == 8) DARK_S256_PROBE(8)
   else if (probe == 16) DARK_S256_PROBE(16)
   else if (probe == 24) DARK_S256_PROBE(24)
+  else if (probe == 32) DARK_S256_PROBE(32)
+  else if (probe == 40) DARK_S256_PROBE(40)
+  else if (probe == 64) DARK_S256_PROBE(64)
+  else if (probe == 72) DARK_S256_PROBE(72)
+  else if (probe == 128) DARK_S256_PROBE(128)
+  else if (probe == 132) DARK_S256_PROBE(132)
   else if (epi == EPI_SWIGLU) DARK_S256(EPI_SWIGLU)
   else if (epi == EPI_BIAS) DARK_S256(EPI_BIAS)
   else DARK_S256(EPI_F32)

@@ -13,7 +13,9 @@ import torch
 from dark_amd import _hip
 
 NAMES = {4: "full kernel", 17: "no DMA issue", 18: "no fragment reads", 19: "no DMA, no fragment reads",
-         20: "no epilogue", 23: "MFMAs + barriers only", 32: "whole-line DMA (same bytes)"}
+         20: "no epilogue", 23: "MFMAs + barriers only", 32: "whole-line DMA (same bytes)", 48: "half of the DMA after the MFMAs",
+         80: "all of the DMA after the MFMAs", 144: "no MFMAs (data movement only)",
+         148: "no MFMAs, no epilogue"}
 
 
 def main():
@@ -48,25 +50,36 @@ def main():
             tiles = 9  # 2208 tiles of 256 x 256 over 256 CUs: 9 rounds
             print(f"K={K:4d} {name:28s}: {med:7.1f} us  ({med / tiles / (K // 32) * 1e3:6.0f} ns per 32-deep K-tile; "
                   f"MFMA-bound at 2.4 GHz: {ideal:6.1f} us)", flush=True)
+        # the builds that move DMA issue behind the MFMAs compute the same thing: bit-identical outputs
+        outs = {}
+        for v in (4, 48, 80):
+            _hip.check(lib.dark_dbg_set_gemm_variant(v))
+            o.zero_()
+            _hip.check(lib.dark_dbg_gemm(1, 2, _hip.ptr(A), _hip.ptr(W), None, _hip.ptr(o), M, N, K, N // 2, st))
+            torch.cuda.synchronize()
+            outs[v] = o.clone()
+        print(f"K={K:4d} DMA-split builds bit-identical to the default: {torch.equal(outs[4], outs[48])} / "
+              f"{torch.equal(outs[4], outs[80])}", flush=True)
         # per-phase cycle sums (probe bit 3; results stay correct): int64 [256 workgroups][8 waves][6]
-        _hip.check(lib.dark_dbg_set_gemm_variant(24))
-        buf = torch.zeros(256 * 8 * 6, dtype=torch.int64, device=dev)
-        for _ in range(3):
-            buf.zero_()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _hip.check(lib.dark_dbg_gemm(1, 2, _hip.ptr(A), _hip.ptr(W), buf.data_ptr(), _hip.ptr(o), M, N, K, N // 2, st))
-            e1.record()
-            torch.cuda.synchronize()
-        t = buf.view(256, 8, 6).double().cpu()
-        print(f"K={K:4d} instrumented launch: {e0.elapsed_time(e1) * 1e3:.1f} us; cycles per 32-deep K-tile and wave "
-              f"(s_memtime ticks; mean over 256 workgroups):")
-        for g, sl in (("group 0 (waves 0-3)", slice(0, 4)), ("group 1 (waves 4-7)", slice(4, 8))):
-            x = t[:, sl, :].reshape(-1, 6)
-            per = (x[:, :5] / x[:, 5:6]).mean(0)
-            print(f"   {g}: LOAD work {per[0]:6.0f} | DMA wait {per[1]:5.0f} | barrier after LOAD {per[2]:5.0f} | "
-                  f"MFMA issue {per[3]:6.0f} | barrier after MFMA {per[4]:5.0f} | sum {per.sum():6.0f}", flush=True)
+        for pv, label in ((24, "default"), (56, "half of the DMA after the MFMAs"), (88, "all of the DMA after the MFMAs")):
+            _hip.check(lib.dark_dbg_set_gemm_variant(pv))
+            buf = torch.zeros(256 * 8 * 6, dtype=torch.int64, device=dev)
+            for _ in range(3):
+                buf.zero_()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _hip.check(lib.dark_dbg_gemm(1, 2, _hip.ptr(A), _hip.ptr(W), buf.data_ptr(), _hip.ptr(o), M, N, K, N // 2, st))
+                e1.record()
+                torch.cuda.synchronize()
+            t = buf.view(256, 8, 6).double().cpu()
+            print(f"K={K:4d} instrumented launch ({label}): {e0.elapsed_time(e1) * 1e3:.1f} us; s_memtime ticks per 32-deep "
+                  f"K-tile and wave, mean over 256 workgroups:")
+            for g, sl in (("group 0 (waves 0-3)", slice(0, 4)), ("group 1 (waves 4-7)", slice(4, 8))):
+                x = t[:, sl, :].reshape(-1, 6)
+                per = (x[:, :5] / x[:, 5:6]).mean(0)
+                print(f"   {g}: LOAD work {per[0]:6.0f} | DMA wait {per[1]:5.0f} | barrier after LOAD {per[2]:5.0f} | "
+                      f"MFMA issue {per[3]:6.0f} | barrier after MFMA {per[4]:5.0f} | sum {per.sum():6.0f}", flush=True)
     lib.dark_dbg_set_gemm_variant(0)
 
 
