@@ -606,12 +606,15 @@ static std::atomic<int> g_gemm_variant{0};
 int gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 void set_p256_nodma(int v);
 void set_s256_probe(int v);
+void set_s256_rows(int v);
 // 3 = timing probe: variant 2 with the main loop's LDS-DMA issue removed (wrong results); 16 + p = timing probe p of
-// gemm_bf16_s256 (gemm256.hip, wrong results): variant 4 with parts of its intervals removed
+// gemm_bf16_s256 (gemm256.hip, wrong results): variant 4 with parts of its intervals removed; 8 / 10 = variant 4 with
+// its tile height forced to 256 / 320 rows (A/B of the two instantiations; other values leave the choice automatic)
 void set_gemm_variant(int v) {
   set_p256_nodma(v == 3);
   set_s256_probe(v >= 16 ? v - 16 : 0);
-  g_gemm_variant.store(v == 3 ? 2 : (v >= 16 ? 4 : v), std::memory_order_relaxed);
+  set_s256_rows(v == 8 ? 256 : (v == 10 ? 320 : 0));
+  g_gemm_variant.store(v == 3 ? 2 : ((v >= 16 || v == 8 || v == 10) ? 4 : v), std::memory_order_relaxed);
 }
 
 // Which kernel serves a bf16 GEMM: 0 = the 128-row kernels of this file, 2 = gemm_bf16_p256, 4 = gemm_bf16_s256.

@@ -268,16 +268,21 @@ constexpr int SBK = 32;
 // per-phase timestamps (tools/probe/gemm_s256_probe.py) showed ~90 cycles per interval of EXPOSED wait for the DMA
 // issued three K-tiles (~1500 cycles) earlier -- L2 / Infinity-Cache latency under a load of 256 CUs x 40 GB/s -- on
 // the LOAD side, which is the critical side of every interval; a fifth buffer lets the DMA run four K-tiles ahead.
-constexpr int s_nbuf(int epi) { return epi == EPI_BIAS ? 4 : 5; }
-constexpr int S_OPER = 256 * SBK * 2;   // 16 KiB per operand K-tile
-constexpr int S_BUF = 2 * S_OPER;       // 32 KiB per K-tile
-constexpr int s_smem(int epi) { return s_nbuf(epi) * S_BUF; }  // 160 KiB (128 KiB + bias for EPI_BIAS)
+// MI = 16-row MFMA tiles per wave: the tile is 32 * MI rows x 256 columns.  MI = 8 is the 256 x 256 tile; MI = 10
+// (320 x 256: 160 accumulator + 56 fragment registers a lane, 243 VGPRs) moves 10 % fewer L2 -> LDS bytes per MAC and
+// quantises M = 23552 better (74 x 24 = 1776 tiles = 6.94 rounds of 256 CUs against 8.63 -> 9); its K-tile is
+// 36 KiB, so four of them fit instead of five.  Measured: gate/up 181.4 vs 186.7 us, K = 3072 642 vs 674 us.
+constexpr int s_nbuf(int epi, int mi) { return (epi == EPI_BIAS || mi > 8) ? 4 : 5; }
+constexpr int S_WOPER = 256 * SBK * 2;                                   // 16 KiB: the weight K-tile
+constexpr int s_aoper(int mi) { return 32 * mi * SBK * 2; }              // the activation K-tile
+constexpr int s_buf(int mi) { return s_aoper(mi) + S_WOPER; }
+constexpr int s_smem(int epi, int mi) { return s_nbuf(epi, mi) * s_buf(mi); }  // 160 KiB (MI = 10: 144; EPI_BIAS: 128 + bias)
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int EPI> struct StoresPerTile;                                   // buffer stores a wave issues per tile
-template <> struct StoresPerTile<EPI_SWIGLU> { static constexpr int N = 8; };
-template <> struct StoresPerTile<EPI_BIAS> { static constexpr int N = 16; };
-template <> struct StoresPerTile<EPI_F32> { static constexpr int N = 32; };
-template <> struct StoresPerTile<EPI_HEAD> { static constexpr int N = 8; };
+template <> struct StoresPerTile<EPI_SWIGLU> { static constexpr int PER_MI = 1; };   // ... per 16-row MFMA tile
+template <> struct StoresPerTile<EPI_BIAS> { static constexpr int PER_MI = 2; };
+template <> struct StoresPerTile<EPI_F32> { static constexpr int PER_MI = 4; };
+template <> struct StoresPerTile<EPI_HEAD> { static constexpr int PER_MI = 1; };
 constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }  // vmcnt(n), nothing else
 }  // namespace
 
@@ -286,25 +291,28 @@ constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 // (results stay correct): per-wave cycle sums of the interval's phases, written through `bias` as int64[grid][8 waves][6]
 // = {LOAD work until its reads have returned, wait for the next K-tile's DMA, barrier wait behind LOAD, MFMA issue,
 // barrier wait behind the MFMAs, K-tiles} (s_memtime costs a few dozen cycles per sample: proportions, not absolutes).
-template <int EPI, int PROBE = 0>
+template <int EPI, int PROBE = 0, int MI = 8>
 __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ bias, void* __restrict__ out, int M,
                                                       int N, int K, int64_t ldo, int tilesM, int tilesN, int ntiles,
                                                       unsigned a_bytes, unsigned w_bytes, unsigned o_bytes,
                                                       const int* __restrict__ m_dev, float hp_c2, float hp_range) {
   constexpr int GM = 8;
-  constexpr int NST = StoresPerTile<EPI>::N;
-  constexpr int NB = s_nbuf(EPI);          // LDS buffers; the DMA runs NB - 1 K-tiles ahead of the reads
-  constexpr int AHEAD_OPS = 4 * (NB - 2);  // DMAs of this wave that are younger than the NEXT K-tile's batch
-  // Pieces of a K-tile's batch that a wave issues in its LOAD interval; the rest follow its MFMAs, in the time it would
-  // otherwise spend at the barrier waiting for the loading group (PROBE bits 5, 6 select 1 and 0: A/B builds).
-  constexpr int QL = (PROBE & 32) ? 1 : ((PROBE & 64) ? 0 : 2);
-  constexpr int WAIT_OPS = AHEAD_OPS - 2 * (2 - QL);  // ... of which 2 * (2 - QL) have not been issued yet at the wait
+  constexpr int TM = 32 * MI, GROWS = 16 * MI;   // tile rows; rows per wave group
+  constexpr int NST = StoresPerTile<EPI>::PER_MI * MI;
+  constexpr int NB = s_nbuf(EPI, MI);      // LDS buffers; the DMA runs NB - 1 K-tiles ahead of the reads
+  constexpr int S_OPER = s_aoper(MI), S_BUF = s_buf(MI);
   constexpr int S_SMEM = NB * S_BUF;
+  // DMA pieces (16 rows x 64 B, one wave-instruction each) of a K-tile: 2 * MI of A, 16 of W.  Every wave brings two W
+  // pieces; the A pieces go NA0 to each wave of group 0 and NA1 to each wave of group 1 (MI = 8: 2 + 2, MI = 10: 3 + 2),
+  // so the two groups issue different numbers of DMAs per batch and carry their own counted waits.
+  constexpr int NA1 = (2 * MI) / 8, NA0 = (2 * MI - 4 * NA1) / 4;
+  static_assert(4 * NA0 + 4 * NA1 == 2 * MI && NA0 >= NA1, "A pieces do not divide over the waves");
+  constexpr int OPS0 = NA0 + 2, OPS1 = NA1 + 2;          // DMAs per batch of a wave in group 0 / 1
   if (m_dev) {  // row count from device memory (never more than the host's M, which sized the buffers)
     const int md = __builtin_amdgcn_readfirstlane(*m_dev);
     M = md < M ? (md > 0 ? md : 0) : M;
-    tilesM = (M + 255) >> 8;
+    tilesM = (M + TM - 1) / TM;
     ntiles = tilesM * tilesN;
   }
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -321,29 +329,35 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   const unsigned kb = (unsigned)K * 2u;
   // piece = 16 rows x 64 B: lane l -> row (l >> 2), position l & 3 holds logical chunk (l & 3) ^ ((l >> 4) & 2)
   const unsigned voff = (unsigned)(lane >> 2) * kb + (unsigned)(((lane & 3) ^ ((lane >> 4) & 2)) << 4);
-  // this wave's pieces q0 .. q1-1 (of 2: one A and one W piece each) of K-tile kt
-  auto stage = [&](int buf, unsigned a0, unsigned w0, int kt, int q0 = 0, int q1 = 2) {
+  // this wave's pieces of K-tile kt: A pieces first (NA0 / NA1 of them), then its two W pieces
+  const int pa0 = grp == 0 ? wave * NA0 : 4 * NA0 + (wave - 4) * NA1;   // first A piece of this wave
+  auto stage = [&](int buf, unsigned a0, unsigned w0, int kt) {
     char* base = smem + buf * S_BUF;
-#pragma unroll
-    for (int q = q0; q < q1; ++q) {
-      const int p = wave * 2 + q;
-      unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
-      if constexpr (PROBE & 16) {
-        // timing probe (WRONG results): the same bytes over two K-tiles, fetched as WHOLE 128-byte lines -- 8 rows x
-        // 128 B per instruction, rows [0,128) on even K-tiles and [128,256) on odd ones -- instead of two 64-byte halves
-        // of every line one K-tile apart
-        so = (unsigned)(p * 8 + (kt & 1) * 128) * kb + (unsigned)(kt >> 1) * 128u +
-             ((unsigned)(lane >> 3) * kb + (unsigned)(lane & 7) * 16u) - voff;
+    if constexpr (NA0 != NA1) {
+      if (grp == 0) {  // the extra A piece of group 0's waves
+        const int p = pa0 + NA1;
+        const unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + p * 1024), 16, voff + (a0 + so), 0, 0, 0);
       }
-      // (the whole offset goes into the VGPR operand: the SGPR offset is EXCLUDED from the descriptor's bounds check)
+    }
+#pragma unroll
+    for (int q = 0; q < NA1; ++q) {
+      const int p = pa0 + q;
+      const unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + p * 1024), 16, voff + (a0 + so), 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = wave * 2 + q;
+      const unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
+      // (the whole offset goes into the VGPR operand: the SGPR offset is EXCLUDED from the descriptor's bounds check)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + S_OPER + p * 1024), 16, voff + (w0 + so), 0, 0, 0);
     }
   };
 
   const int frow = lane & 15, fq = lane >> 4;
   const int fch = (fq ^ ((frow >> 2) & 2)) << 4;
-  const int a_rd = (grp * 128 + frow) * 64 + fch, w_rd = S_OPER + (wn * 64 + frow) * 64 + fch;
+  const int a_rd = (grp * GROWS + frow) * 64 + fch, w_rd = S_OPER + (wn * 64 + frow) * 64 + fch;
 
   auto tile_of = [&](int id, int& tm, int& tn) {
     const int per_group = GM * tilesN;
@@ -362,18 +376,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   {
     int tm, tn;
     tile_of(d_id, tm, tn);
-    d_a0 = (unsigned)tm * 256u * kb;
+    d_a0 = (unsigned)tm * (unsigned)TM * kb;
     d_w0 = (unsigned)tn * 256u * kb;
   }
   bool probe_warm = false;  // (PROBE builds: set once the pipeline is primed)
-  // pieces [q0, q1) of the cursor's K-tile; the cursor moves on with the last piece
-  auto stage_next = [&](int q0 = 0, int q1 = 2) {
+  auto stage_next = [&]() {
     if constexpr (PROBE & 1) { if (probe_warm) return; }
-    if (d_id < ntiles) stage(d_buf, d_a0, d_w0, d_kt, q0, q1);
+    if (d_id < ntiles) stage(d_buf, d_a0, d_w0, d_kt);
     else {  // past the last tile: keep the per-phase DMA count constant (the counted waits rely on it)
-      stage(d_buf, 0xF0000000u, 0xF0000000u, 0, q0, q1);  // out of range: nothing is fetched, zeros land in a dead buffer
+      stage(d_buf, 0xF0000000u, 0xF0000000u, 0);  // out of range: nothing is fetched, zeros land in a dead buffer
     }
-    if (q1 < 2) return;
     d_buf = d_buf + 1 == NB ? 0 : d_buf + 1;
     if (++d_kt == KT) {
       d_kt = 0;
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
       if (d_id < ntiles) {
         int tm, tn;
         tile_of(d_id, tm, tn);
-        d_a0 = (unsigned)tm * 256u * kb;
+        d_a0 = (unsigned)tm * (unsigned)TM * kb;
         d_w0 = (unsigned)tn * 256u * kb;
       }
     }
@@ -389,12 +401,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
 #pragma unroll
   for (int i = 0; i < NB - 1; ++i) stage_next();
   probe_warm = true;
-  __builtin_amdgcn_s_waitcnt(waitcnt_vm(AHEAD_OPS));  // K-tile 0 has landed (this wave's pieces)
+  // K-tile 0 has landed (this wave's pieces): NB - 2 younger batches are still in flight
+  if (OPS0 == OPS1 || grp == 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS1 * (NB - 2)));
+  else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS0 * (NB - 2)));
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one interval behind group 0
 
-  f32x4 acc[P_NI][P_MI];
-  bf16x8 fa[P_MI], fw[P_NI];
+  f32x4 acc[P_NI][MI];
+  bf16x8 fa[MI], fw[P_NI];
   int rbuf = 0;  // LDS buffer of the K-tile being read
 
   // epilogue of the tile at (m0, n0): this lane owns row (lane & 15) of each 16-row tile, 4 consecutive columns of
@@ -405,13 +419,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
 #pragma unroll
       for (int j = 0; j < P_NI; ++j)
 #pragma unroll
-        for (int i = 0; i < P_MI; ++i) sacc += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
+        for (int i = 0; i < MI; ++i) sacc += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
       if (sacc == 12345.678f) __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){0u, 0u, 0u, 0u}, ro, 0u, 0, 0);
       return;
     }
 #pragma unroll
-    for (int mi = 0; mi < P_MI; ++mi) {
-      const int m = m0 + grp * 128 + mi * 16 + frow;
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + grp * GROWS + mi * 16 + frow;
       if constexpr (EPI == EPI_SWIGLU) {
         float v[2][4];
 #pragma unroll
@@ -535,21 +549,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
 #pragma unroll
         for (int j = 0; j < P_NI; ++j) fw[j] = *(const bf16x8*)(ws + j * 1024);
 #pragma unroll
-        for (int i = 0; i < P_MI; ++i) fa[i] = *(const bf16x8*)(as + i * 1024);
+        for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(as + i * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (QL > 0) stage_next(0, QL);  // K-tile NB - 1 phases ahead, into the buffer both groups finished reading one interval ago
+      stage_next();  // K-tile NB - 1 phases ahead, into the buffer both groups finished reading one interval ago
       __builtin_amdgcn_sched_barrier(0);
-      // this wave's pieces of the NEXT K-tile have landed: its batch is followed by NB - 2 younger batches (4 DMAs
-      // each) and, for the NB - 2 phases behind an epilogue, by that epilogue's NST stores (the batch of K-tile kt + 1
-      // was issued NB - 2 intervals before this one; the stores at kt = 0, in front of that interval's batch)
+      // this wave's pieces of the NEXT K-tile have landed: its batch is followed by NB - 2 younger batches (OPS0 / OPS1
+      // DMAs each) and, for the NB - 2 phases behind an epilogue, by that epilogue's NST stores (the batch of K-tile
+      // kt + 1 was issued NB - 2 intervals before this one; the stores at kt = 0, in front of that interval's batch)
       long long t1 = 0, t2 = 0;
       if constexpr (PROBE & 8) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: the fragment reads have returned
         t1 = now();
       }
-      if (pending && kt < NB - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(WAIT_OPS + NST) & 0xF0FF);  // + lgkmcnt(0)
-      else __builtin_amdgcn_s_waitcnt(waitcnt_vm(WAIT_OPS) & 0xF0FF);
+      if (OPS0 == OPS1 || grp == 1) {
+        if (pending && kt < NB - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS1 * (NB - 2) + NST) & 0xF0FF);  // + lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS1 * (NB - 2)) & 0xF0FF);
+      } else {
+        if (pending && kt < NB - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS0 * (NB - 2) + NST) & 0xF0FF);
+        else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS0 * (NB - 2)) & 0xF0FF);
+      }
       if constexpr (PROBE & 8) t2 = now();
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -557,20 +576,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
       // ================= MFMA interval =================
       if constexpr (PROBE & 128) {  // timing probe: data movement only (one MFMA keeps the fragments alive)
         acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kt & 3], fa[kt & 7], kt ? acc[0][0] : (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (kt == 0) {
+#pragma unroll
+          for (int j = 0; j < P_NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+              if (i + j) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
       } else if (kt == 0) {
 #pragma unroll
         for (int j = 0; j < P_NI; ++j)
 #pragma unroll
-          for (int i = 0; i < P_MI; ++i)
+          for (int i = 0; i < MI; ++i)
             acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       } else {
 #pragma unroll
         for (int j = 0; j < P_NI; ++j)
 #pragma unroll
-          for (int i = 0; i < P_MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+          for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (QL < 2) stage_next(QL, 2);
       __builtin_amdgcn_sched_barrier(0);
       const long long t4 = now();
       __builtin_amdgcn_s_barrier();
@@ -580,7 +604,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
       }
       rbuf = rbuf + 1 == NB ? 0 : rbuf + 1;
     }
-    pm0 = tm * 256;
+    pm0 = tm * TM;
     pn0 = tn * 256;
     pending = true;
   }
@@ -651,63 +675,75 @@ int launch_gemm_p256(int epi, const void* A, const void* W, const float* bias, v
 bool s256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias) {
   if (!p256_supports(epi, M, N, K, ldo, out, bias) || K < 128) return false;
   const int64_t es = epi == EPI_F32 ? 4 : 2;
-  if (((int64_t)M + 256) * ldo * es >= 0xE0000000ll) return false;  // 32-bit byte offsets of the buffer stores
-  if (epi == EPI_BIAS && (cdiv(N, 256) * 256 * 4 > 160 * 1024 - s_smem(EPI_BIAS) || ((uintptr_t)bias & 3))) return false;
+  if (((int64_t)M + 320) * ldo * es >= 0xE0000000ll) return false;  // 32-bit byte offsets of the buffer stores
+  if (epi == EPI_BIAS && (cdiv(N, 256) * 256 * 4 > 160 * 1024 - s_smem(EPI_BIAS, 8) || ((uintptr_t)bias & 3))) return false;
   return true;
 }
 
 static std::atomic<int> g_s256_probe{0};
 void set_s256_probe(int v) { g_s256_probe.store(v); }
+static std::atomic<int> g_s256_rows{0};   // 0 = automatic, 256 / 320 = forced tile height (A/B hook)
+void set_s256_rows(int v) { g_s256_rows.store(v); }
+
+static int cu_count(int* cus) {
+  int dev = 0;
+  DARK_CHECK_HIP(hipGetDevice(&dev));
+  DARK_CHECK_HIP(hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev));
+  return DARK_OK;
+}
+
+// 16-row MFMA tiles per wave: 8 (256 x 256 tile) or 10 (320 x 256).  Per row the two run at the same rate within 2 %
+// (tools/gemm_ab.py --variants 8,10: its fewer bytes per MAC pay for its four instead of five LDS buffers), so the
+// choice is tile quantisation: the height that needs fewer row-rounds over the CUs.
+static int s256_pick_mi(int epi, int M, int tilesN, int cus) {
+  if (epi == EPI_BIAS) return 8;   // (keeps its bias vector behind four 32-KiB buffers)
+  const int forced = g_s256_rows.load(std::memory_order_relaxed);
+  if (forced == 256) return 8;
+  if (forced == 320) return 10;
+  const double c8 = (double)cdiv(cdiv(M, 256) * tilesN, cus) * 8.0;
+  const double c10 = (double)cdiv(cdiv(M, 320) * tilesN, cus) * 10.0 * 0.98;
+  return c10 < c8 ? 10 : 8;
+}
+
+// one launch of gemm_bf16_s256<E, PB, MI_> with everything the kernel derives from the tile height
+#define DARK_S256_LAUNCH(E, PB, MI_, BIAS_PTR, MDEV, C2, RANGE)                                                       \
+  {                                                                                                                   \
+    const int tilesM = cdiv(M, 32 * MI_), ntiles = tilesM * tilesN, grid = min(ntiles, cus);                          \
+    const int smem = s_smem(E, MI_) + (E == EPI_BIAS ? tilesN * 256 * 4 : 0);                                         \
+    static SmemOptIn optin;                                                                                           \
+    DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<E, PB, MI_>, smem, st));                                        \
+    hipLaunchKernelGGL((gemm_bf16_s256<E, PB, MI_>), dim3(grid), dim3(512), smem, st, (const bf16_t*)A,               \
+                       (const bf16_t*)W, BIAS_PTR, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes, \
+                       MDEV, C2, RANGE);                                                                              \
+  }
+#define DARK_S256_EITHER(E, MDEV, C2, RANGE)                                \
+  if (mi == 10) DARK_S256_LAUNCH(E, 0, 10, bias, MDEV, C2, RANGE)           \
+  else DARK_S256_LAUNCH(E, 0, 8, bias, MDEV, C2, RANGE)
 
 int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                      int64_t ldo, int w_rows, hipStream_t st) {
   DARK_CHECK_ARG(s256_supports(epi, M, N, K, ldo, out, bias), "gemm_s256: unsupported shape M=%d N=%d K=%d", M, N, K);
-  const int tilesM = cdiv(M, 256), tilesN = cdiv(N, 256);
-  const int ntiles = tilesM * tilesN;
-  int dev = 0, cus = 0;
-  DARK_CHECK_HIP(hipGetDevice(&dev));
-  DARK_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int grid = min(ntiles, cus);
+  const int tilesN = cdiv(N, 256);
+  int cus = 0;
+  DARK_TRY(cu_count(&cus));
   const int64_t es = epi == EPI_F32 ? 4 : 2;
   const unsigned a_bytes = (unsigned)((int64_t)M * K * 2), w_bytes = (unsigned)((int64_t)w_rows * K * 2);
   const unsigned o_bytes = (unsigned)((int64_t)M * ldo * es);
-  const int smem = s_smem(epi) + (epi == EPI_BIAS ? tilesN * 256 * 4 : 0);
-#define DARK_S256(E)                                                                                               \
-  {                                                                                                                \
-    static SmemOptIn optin;                                                                                        \
-    DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<E>, smem, st));                                              \
-    hipLaunchKernelGGL((gemm_bf16_s256<E>), dim3(grid), dim3(512), smem, st, (const bf16_t*)A, (const bf16_t*)W,   \
-                       bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes,                 \
-                       (const int*)nullptr, 0.f, 0.f);                                                             \
-  }
-#define DARK_S256_PROBE(PB)                                                                                        \
-  {                                                                                                                \
-    static SmemOptIn optin;                                                                                        \
-    DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<EPI_SWIGLU, PB>, smem, st));                                 \
-    hipLaunchKernelGGL((gemm_bf16_s256<EPI_SWIGLU, PB>), dim3(grid), dim3(512), smem, st, (const bf16_t*)A,        \
-                       (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes, \
-                       (const int*)nullptr, 0.f, 0.f);                                                             \
-  }
-  const int probe = epi == EPI_SWIGLU ? g_s256_probe.load() : 0;
-  if (probe == 1) DARK_S256_PROBE(1)
-  else if (probe == 2) DARK_S256_PROBE(2)
-  else if (probe == 3) DARK_S256_PROBE(3)
-  else if (probe == 4) DARK_S256_PROBE(4)
-  else if (probe == 7) DARK_S256_PROBE(7)
-  else if (probe == 8) DARK_S256_PROBE(8)
-  else if (probe == 16) DARK_S256_PROBE(16)
-  else if (probe == 24) DARK_S256_PROBE(24)
-  else if (probe == 32) DARK_S256_PROBE(32)
-  else if (probe == 40) DARK_S256_PROBE(40)
-  else if (probe == 64) DARK_S256_PROBE(64)
-  else if (probe == 72) DARK_S256_PROBE(72)
-  else if (probe == 128) DARK_S256_PROBE(128)
-  else if (probe == 132) DARK_S256_PROBE(132)
-  else if (epi == EPI_SWIGLU) DARK_S256(EPI_SWIGLU)
-  else if (epi == EPI_BIAS) DARK_S256(EPI_BIAS)
-  else DARK_S256(EPI_F32)
-#undef DARK_S256_PROBE
-#undef DARK_S256
+  const int mi = s256_pick_mi(epi, M, tilesN, cus);
+  const int probe = epi == EPI_SWIGLU ? g_s256_probe.load() : 0;   // timing probes: gate/up flavour, 256-row tile
+  const int* no_mdev = nullptr;
+  if (probe == 1) DARK_S256_LAUNCH(EPI_SWIGLU, 1, 8, bias, no_mdev, 0.f, 0.f)
+  else if (probe == 2) DARK_S256_LAUNCH(EPI_SWIGLU, 2, 8, bias, no_mdev, 0.f, 0.f)
+  else if (probe == 3) DARK_S256_LAUNCH(EPI_SWIGLU, 3, 8, bias, no_mdev, 0.f, 0.f)
+  else if (probe == 4) DARK_S256_LAUNCH(EPI_SWIGLU, 4, 8, bias, no_mdev, 0.f, 0.f)
+  else if (probe == 7) DARK_S256_LAUNCH(EPI_SWIGLU, 7, 8, bias, no_mdev, 0.f, 0.f)
+  else if (probe == 8) DARK_S256_LAUNCH(EPI_SWIGLU, 8, 8, bias, no_mdev, 0.f, 0.f)
+  else if (probe == 128) DARK_S256_LAUNCH(EPI_SWIGLU, 128, 8, bias, no_mdev, 0.f, 0.f)
+  else if (probe == 132) DARK_S256_LAUNCH(EPI_SWIGLU, 132, 8, bias, no_mdev, 0.f, 0.f)
+  else if (probe == 9) DARK_S256_LAUNCH(EPI_SWIGLU, 8, 10, bias, no_mdev, 0.f, 0.f)   // (per-phase sums of the 320-row tile)
+  else if (epi == EPI_SWIGLU) { DARK_S256_EITHER(EPI_SWIGLU, no_mdev, 0.f, 0.f) }
+  else if (epi == EPI_BIAS) DARK_S256_LAUNCH(EPI_BIAS, 0, 8, bias, no_mdev, 0.f, 0.f)
+  else { DARK_S256_EITHER(EPI_F32, no_mdev, 0.f, 0.f) }
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }
@@ -717,33 +753,24 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
 bool head_gemm_supports(int M, int N, int K) {
   if (M <= 0 || N < 256 || K % 64 != 0 || K < 128) return false;
   if ((int64_t)M * K * 2 >= (1ll << 31) || ((int64_t)N + 256) * K * 2 >= (1ll << 31)) return false;
-  if (((int64_t)M + 256) * (cdiv(N, 256) * 4) * 16 >= 0xE0000000ll) return false;
+  if (((int64_t)M + 320) * (cdiv(N, 256) * 4) * 16 >= 0xE0000000ll) return false;
   return true;
-}
-
-static int cu_count(int* cus) {
-  int dev = 0;
-  DARK_CHECK_HIP(hipGetDevice(&dev));
-  DARK_CHECK_HIP(hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev));
-  return DARK_OK;
 }
 
 int launch_gemm_head(const void* A, const void* W, void* records, int M, int N, int K, float c2, float range,
                      const int* m_dev, int w_rows, hipStream_t st) {
   DARK_CHECK_ARG(A && W && records && head_gemm_supports(M, N, K), "gemm_head: unsupported shape M=%d N=%d K=%d", M, N, K);
   DARK_CHECK_ARG(((uintptr_t)records & 15) == 0 && c2 > 0.f && range > 0.f, "gemm_head: bad argument");
-  const int tilesM = cdiv(M, 256), tilesN = cdiv(N, 256);
-  const int ntiles = tilesM * tilesN;
+  const int tilesN = cdiv(N, 256);
   int cus = 0;
   DARK_TRY(cu_count(&cus));
-  const int grid = min(ntiles, cus);
   const unsigned a_bytes = (unsigned)((int64_t)M * K * 2), w_bytes = (unsigned)((int64_t)w_rows * K * 2);
   const unsigned o_bytes = (unsigned)((int64_t)M * tilesN * 4 * 16);
-  static SmemOptIn optin;
-  DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<EPI_HEAD>, s_smem(EPI_HEAD), st));
-  hipLaunchKernelGGL((gemm_bf16_s256<EPI_HEAD>), dim3(grid), dim3(512), s_smem(EPI_HEAD), st, (const bf16_t*)A, (const bf16_t*)W,
-                     (const float*)nullptr, records, M, N, K, (int64_t)0, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes,
-                     m_dev, c2, range);
+  const int mi = s256_pick_mi(EPI_HEAD, M, tilesN, cus);
+  const float* bias = nullptr;
+  void* out = records;
+  const int64_t ldo = 0;
+  DARK_S256_EITHER(EPI_HEAD, m_dev, c2, range)
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }
@@ -752,20 +779,18 @@ int launch_gemm_s256_devrows(const void* A, const void* W, void* out, int M, int
                              int w_rows, hipStream_t st) {
   DARK_CHECK_ARG(s256_supports(EPI_F32, M, N, K, ldo, out, nullptr) && m_dev, "gemm_s256_devrows: unsupported shape M=%d N=%d K=%d",
                  M, N, K);
-  const int tilesM = cdiv(M, 256), tilesN = cdiv(N, 256);
-  const int ntiles = tilesM * tilesN;
+  const int tilesN = cdiv(N, 256);
   int cus = 0;
   DARK_TRY(cu_count(&cus));
-  const int grid = min(ntiles, cus);
   const unsigned a_bytes = (unsigned)((int64_t)M * K * 2), w_bytes = (unsigned)((int64_t)w_rows * K * 2);
   const unsigned o_bytes = (unsigned)((int64_t)M * ldo * 4);
-  static SmemOptIn optin;
-  DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<EPI_F32>, s_smem(EPI_F32), st));
-  hipLaunchKernelGGL((gemm_bf16_s256<EPI_F32>), dim3(grid), dim3(512), s_smem(EPI_F32), st, (const bf16_t*)A, (const bf16_t*)W,
-                     (const float*)nullptr, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes, m_dev, 0.f,
-                     0.f);
+  const int mi = s256_pick_mi(EPI_F32, M, tilesN, cus);
+  const float* bias = nullptr;
+  DARK_S256_EITHER(EPI_F32, m_dev, 0.f, 0.f)
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }
+#undef DARK_S256_EITHER
+#undef DARK_S256_LAUNCH
 
 }  // namespace dark

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of the bf16 GEMM kernels in ONE process (interleaved rounds, same device, random operands): variant 1 = the
-128-row kernels of gemm.hip, 2 = the persistent 256 x 256 kernel of gemm256.hip, 4 = its staggered form
-(a variant serves the shapes it supports and falls back to variant 1 elsewhere).  Checks variant 2 against an
+128-row kernels of gemm.hip, 2 = the persistent 256 x 256 kernel of gemm256.hip, 4 = its staggered form with the
+automatic tile height, 8 / 10 = the staggered form with 256 / 320-row tiles (a variant serves the shapes it supports and
+falls back to variant 1 elsewhere).  Checks variant 2 against an
 fp64 reference on ragged row counts first.  Usage (GPU box): python tools/gemm_ab.py [--rows 23552] [--rounds 5]"""
 import argparse
 import os

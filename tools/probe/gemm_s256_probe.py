@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where an interval of gemm_bf16_s256 goes: times the gate/up launch (M = 23552, N = 6144) with parts of the kernel
-removed (timing-only builds, WRONG results; dark_dbg_set_gemm_variant(16 + p)): p bit 0 = no LDS-DMA issue in the steady
-state, bit 1 = no fragment reads after the first K-tile, bit 2 = no epilogue, bit 4 = the DMA fetches whole 128-byte lines (same bytes, other order).  One process, interleaved rounds.
+removed (timing-only builds of the 256-row tile, WRONG results; dark_dbg_set_gemm_variant(16 + p)): p bit 0 = no LDS-DMA
+issue in the steady state, bit 1 = no fragment reads after the first K-tile, bit 2 = no epilogue, bit 7 = no MFMAs; then
+the per-phase s_memtime sums of both tile heights (correct results).  One process, interleaved rounds.
 Usage (GPU box): python tools/probe/gemm_s256_probe.py [--iters 40] [--rounds 5]"""
 import argparse
 import os
@@ -12,10 +13,9 @@ import torch
 
 from dark_amd import _hip
 
-NAMES = {4: "full kernel", 17: "no DMA issue", 18: "no fragment reads", 19: "no DMA, no fragment reads",
-         20: "no epilogue", 23: "MFMAs + barriers only", 32: "whole-line DMA (same bytes)", 48: "half of the DMA after the MFMAs",
-         80: "all of the DMA after the MFMAs", 144: "no MFMAs (data movement only)",
-         148: "no MFMAs, no epilogue"}
+NAMES = {8: "full kernel, 256-row tile", 10: "full kernel, 320-row tile", 17: "no DMA issue",
+         18: "no fragment reads", 19: "no DMA, no fragment reads", 20: "no epilogue", 23: "MFMAs + barriers only",
+         144: "no MFMAs (data movement only)", 148: "no MFMAs, no epilogue"}
 
 
 def main():
@@ -47,21 +47,11 @@ def main():
         for v, name in NAMES.items():
             ts = sorted(times[v])
             med = ts[len(ts) // 2] * 1e3
-            tiles = 9  # 2208 tiles of 256 x 256 over 256 CUs: 9 rounds
+            tiles = 7 if v == 10 else 9  # 2208 tiles of 256 x 256 (1776 of 320 x 256) over 256 CUs: 9 (7) rounds
             print(f"K={K:4d} {name:28s}: {med:7.1f} us  ({med / tiles / (K // 32) * 1e3:6.0f} ns per 32-deep K-tile; "
                   f"MFMA-bound at 2.4 GHz: {ideal:6.1f} us)", flush=True)
-        # the builds that move DMA issue behind the MFMAs compute the same thing: bit-identical outputs
-        outs = {}
-        for v in (4, 48, 80):
-            _hip.check(lib.dark_dbg_set_gemm_variant(v))
-            o.zero_()
-            _hip.check(lib.dark_dbg_gemm(1, 2, _hip.ptr(A), _hip.ptr(W), None, _hip.ptr(o), M, N, K, N // 2, st))
-            torch.cuda.synchronize()
-            outs[v] = o.clone()
-        print(f"K={K:4d} DMA-split builds bit-identical to the default: {torch.equal(outs[4], outs[48])} / "
-              f"{torch.equal(outs[4], outs[80])}", flush=True)
         # per-phase cycle sums (probe bit 3; results stay correct): int64 [256 workgroups][8 waves][6]
-        for pv, label in ((24, "default"), (56, "half of the DMA after the MFMAs"), (88, "all of the DMA after the MFMAs")):
+        for pv, label in ((24, "256-row tile"), (25, "320-row tile")):
             _hip.check(lib.dark_dbg_set_gemm_variant(pv))
             buf = torch.zeros(256 * 8 * 6, dtype=torch.int64, device=dev)
             for _ in range(3):
