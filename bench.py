@@ -195,15 +195,15 @@ def main():
         "forward_mfma_frac": round(alg_flops * args.steps * world / dt / 1e12 / (peak * world), 4),
         # ... and the FLOPs this build executes (last layer's o_proj / MLP on the masked rows only)
         "forward_mfma_frac_executed": round(exe_flops * args.steps * world / dt / 1e12 / (peak * world), 4),
-        "roofline": {"bound": "mfma", "kernel": (({0: "gemm_bf16_s256<2>", 4: "gemm_bf16_s256<2>", 2: "gemm_bf16_p256<2, false>"}.get(
+        "roofline": {"bound": "mfma", "kernel": (({0: "gemm_bf16_s256<2, 0, 10>", 4: "gemm_bf16_s256<2, 0, 10>", 2: "gemm_bf16_p256<2, false>"}.get(
                                     args.gemm_variant, "gemm_bf16_kernel16<2, 192>") if args.dtype == "bf16" else "gemm_f32_kernel<2>")
                                 + f" = EPI_SWIGLU (gate/up projection + SiLU*up, the {rows_full}-row launches of layers 0..L-2, "
                                   "N=6144, K=768)"),
                      "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4),
                      # HBM-side bytes per launch from rocprofv3 PMC (FETCH_SIZE doubled per the gfx950 note, +
-                     # WRITE_SIZE), separate passes, profiles/r02a_pmc.txt; valid for the default shape and kernel
-                     "traffic": 470.5e6 if (args.dtype == "bf16" and args.batch == 1024 and args.gemm_variant == 0) else None,
+                     # WRITE_SIZE), separate passes, profiles/r02zh_pmc.txt; valid for the default shape and kernel
+                     "traffic": 453.5e6 if (args.dtype == "bf16" and args.batch == 1024 and args.gemm_variant == 0) else None,
                      "algorithmic_bytes": 2.0 * (half * 46 * 768 + 6144 * 768 + half * 46 * 3072),
                      "launches": n.value,
                      "avg_launch_ms": round(ms.value / max(n.value, 1), 4)},
