@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=0, choices=[0, 1, 2, 4, 5],
                     help="A/B hook: 0 = the library's choice, 1 = 128-row GEMM kernels only, 2 / 4 = the persistent 256x256 "
                          "kernel (plain / staggered) wherever it supports the shape")
+    ap.add_argument("--residual-fp32", action="store_true",
+                    help="A/B: carry the bf16 model's residual stream in fp32 (default: the model dtype, as the "
+                         "reference's bf16 model does)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on ONE card: every rank uses cuda:0 and the collectives run over gloo (a functional "
                          "rehearsal of the multi-GPU path, not a measurement)")
@@ -112,6 +115,7 @@ def main():
                       pad_token_id=synth.END)
     weights = synth.make_weights(cfg, seed=0)
     model = DreamModel_length(cfg)
+    model.residual_in_fp32 = bool(args.residual_fp32)
     model.load_state_dict(weights, strict=True)
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = model.to(dev).to(tdt)
@@ -189,7 +193,8 @@ def main():
         "config": {"workload": "BASELINE config 2: FB15k-237 mixed deductive+abductive eval, default DARK shape "
                                "(10L d768 ff3072 H8, V=15080, N=46)",
                    "batch_per_gpu": args.batch, "denoise_steps": args.denoise_steps, "temperature": 0.1,
-                   "top_p": 0.9, "alg": "entropy", "parallelism": f"dp{world}", "weights": "random-init"},
+                   "top_p": 0.9, "alg": "entropy", "parallelism": f"dp{world}", "weights": "random-init",
+                   "residual_stream": "f32" if (args.residual_fp32 or args.dtype == "f32") else "bf16"},
         "value_skip_noop_steps": round(args.batch * world * args.steps / dt_skip, 2),
         # SURVEY 8(d)'s algorithmic FLOPs (every row through every layer, head on masked rows) over the dense peak ...
         "forward_mfma_frac": round(alg_flops * args.steps * world / dt / 1e12 / (peak * world), 4),

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libdark_hip.so")
 DARK_OK, DARK_ERR_ARG, DARK_ERR_HIP, DARK_ERR_UNSUPPORTED = 0, 1, 2, 3
 DARK_F32, DARK_BF16 = 0, 1
 CONF_PROB, CONF_MARGIN, CONF_NEG_ENTROPY = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 SHARD_PART_BYTES = 280
 
 
@@ -30,7 +30,7 @@ class LayerWeights(C.Structure):
 class ModelDesc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("vocab", C.c_int32), ("vocab_pad", C.c_int32), ("d", C.c_int32),
                 ("ff", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("head_dim", C.c_int32),
-                ("max_pos", C.c_int32), ("rms_eps", C.c_float), ("embed", C.c_void_p),
+                ("max_pos", C.c_int32), ("rms_eps", C.c_float), ("resid_dtype", C.c_int32), ("embed", C.c_void_p),
                 ("final_norm", C.c_void_p), ("lm_head", C.c_void_p), ("rope_cos", C.c_void_p),
                 ("rope_sin", C.c_void_p), ("layers", C.POINTER(LayerWeights))]
 
@@ -43,7 +43,8 @@ class Gpt2LayerWeights(C.Structure):
 class Gpt2Desc(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("vocab", C.c_int32), ("vocab_pad", C.c_int32), ("d", C.c_int32),
                 ("ff", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("head_dim", C.c_int32),
-                ("n_positions", C.c_int32), ("ln_eps", C.c_float), ("wte", C.c_void_p), ("wpe", C.c_void_p),
+                ("n_positions", C.c_int32), ("ln_eps", C.c_float), ("resid_dtype", C.c_int32), ("wte", C.c_void_p),
+                ("wpe", C.c_void_p),
                 ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p), ("ident_cos", C.c_void_p), ("ident_sin", C.c_void_p),
                 ("layers", C.POINTER(Gpt2LayerWeights))]
 
@@ -141,16 +142,16 @@ SIGNATURES = {
                                      C.c_void_p]),
     "dark_dbg_gemm_resid_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_float, C.c_void_p]),
-    "dark_dbg_rmsnorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    "dark_dbg_rmsnorm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_int, C.c_float, C.c_void_p]),
     "dark_gpt2_forward_workspace_bytes": (C.c_size_t, [C.POINTER(Gpt2Desc), C.c_int, C.c_int]),
     "dark_gpt2_forward_hidden": (C.c_int, [C.POINTER(Gpt2Desc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "dark_gpt2_lm_head_rows": (C.c_int, [C.POINTER(Gpt2Desc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_int64, C.c_void_p]),
-    "dark_dbg_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                     C.c_int, C.c_int, C.c_float, C.c_void_p]),
-    "dark_dbg_embed": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+    "dark_dbg_layernorm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "dark_dbg_embed": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p]),
 }
 

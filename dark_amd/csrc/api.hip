@@ -30,6 +30,8 @@ static int check_model(const dark_model_desc* m) {
   DARK_CHECK_ARG(m->n_layers >= 0 && (m->n_layers == 0 || m->layers), "layers missing");
   DARK_CHECK_ARG(m->embed && m->final_norm && m->lm_head && m->rope_cos && m->rope_sin, "null weight pointer");
   DARK_CHECK_ARG(m->max_pos >= 1, "max_pos=%d", m->max_pos);
+  DARK_CHECK_ARG(m->resid_dtype == DARK_F32 || (m->resid_dtype == DARK_BF16 && m->dtype == DARK_BF16),
+                 "resid_dtype %d with model dtype %d (fp32 always, bf16 for bf16 models)", m->resid_dtype, m->dtype);
   return DARK_OK;
 }
 
@@ -57,13 +59,15 @@ static FwdWs carve_fwd(const dark_model_desc* m, size_t rows, char* base) {
 // profiles/r02q_rowpanel_ab.txt) -- its 246 workgroups run in lockstep, so the 180 MB residual read-modify-write of all
 // epilogues hits HBM at once with no MFMA work left to hide it, where the multi-round 128 x 192 kernel overlaps
 // one tile's epilogue with its neighbours' main loops.
-static int resid_gemm_norm(const dark_model_desc* m, const void* A, const void* W, float* hidden, const float* ln,
+static int resid_gemm_norm(const dark_model_desc* m, const void* A, const void* W, void* hidden, const float* ln,
                            void* xn, int M, int K, hipStream_t st) {
   const int d = m->d;
-  if (m->dtype == DARK_BF16 && gemm_variant() == 5 && rowpanel_supports(M, d, K, A, W, hidden, ln, ln ? xn : nullptr))
-    return launch_gemm_resid_norm(A, W, hidden, ln, ln ? xn : nullptr, M, K, m->rms_eps, st);
-  DARK_TRY(launch_gemm(m->dtype, EPI_RESID, A, W, nullptr, hidden, M, d, K, d, st));
-  if (ln) DARK_TRY(launch_rmsnorm(m->dtype, hidden, ln, xn, nullptr, M, M, d, m->rms_eps, st));
+  if (m->dtype == DARK_BF16 && m->resid_dtype == DARK_F32 && gemm_variant() == 5 &&
+      rowpanel_supports(M, d, K, A, W, hidden, ln, ln ? xn : nullptr))
+    return launch_gemm_resid_norm(A, W, (float*)hidden, ln, ln ? xn : nullptr, M, K, m->rms_eps, st);
+  const int epi = m->resid_dtype == DARK_BF16 ? EPI_RESID_H : EPI_RESID;
+  DARK_TRY(launch_gemm(m->dtype, epi, A, W, nullptr, hidden, M, d, K, d, st));
+  if (ln) DARK_TRY(launch_rmsnorm(m->dtype, m->resid_dtype, hidden, ln, xn, nullptr, M, M, d, m->rms_eps, st));
   return DARK_OK;
 }
 
@@ -71,7 +75,7 @@ static int resid_gemm_norm(const dark_model_desc* m, const void* A, const void* 
 // (o_proj, residual, norm, MLP, residual) only matters for the rows the head will read and is done by forward_tail.
 static int forward_hidden(const dark_model_desc* m, const int64_t* ids, const int32_t* pos,
                           const uint8_t* key_mask, int B, int N, void* workspace, size_t ws_bytes,
-                          float* hidden, hipStream_t st, bool tail_rows = false) {
+                          void* hidden, hipStream_t st, bool tail_rows = false) {
   DARK_TRY(check_model(m));
   DARK_CHECK_ARG(B > 0 && N > 0 && N <= 128, "forward: B=%d N=%d (N must be in [1,128])", B, N);
   DARK_CHECK_ARG((int64_t)B * N < (1ll << 30), "forward: B*N too large");
@@ -83,9 +87,9 @@ static int forward_hidden(const dark_model_desc* m, const int64_t* ids, const in
 
   if (m->n_layers > 0) {  // embedding + the first layer's input norm in one pass over the gathered rows
     DARK_CHECK_ARG(m->layers[0].ln1, "layer 0: null weight");
-    DARK_TRY(launch_embed_norm(m->dtype, ids, m->embed, hidden, M, d, m->vocab, m->layers[0].ln1, m->rms_eps, w.xn, st));
+    DARK_TRY(launch_embed_norm(m->dtype, m->resid_dtype, ids, m->embed, hidden, M, d, m->vocab, m->layers[0].ln1, m->rms_eps, w.xn, st));
   } else {
-    DARK_TRY(launch_embed(m->dtype, ids, m->embed, hidden, M, d, m->vocab, st));
+    DARK_TRY(launch_embed(m->dtype, m->resid_dtype, ids, m->embed, hidden, M, d, m->vocab, st));
   }
   for (int l = 0; l < m->n_layers; ++l) {
     const dark_layer_weights& L = m->layers[l];
@@ -109,7 +113,7 @@ static int forward_hidden(const dark_model_desc* m, const int64_t* ids, const in
 // hidden_rows[r] = what the full body leaves in hidden[rows[r]], bit for bit -- every GEMM output element is the same
 // K-ordered dot product whichever rows share its tile.  The compact operands reuse the (now dead) xn / qkv / act regions.
 static int forward_tail(const dark_model_desc* m, int B, int N, const int32_t* rows, int R, void* workspace,
-                        size_t ws_bytes, const float* hidden, float* hidden_rows, hipStream_t st) {
+                        size_t ws_bytes, const void* hidden, void* hidden_rows, hipStream_t st) {
   DARK_TRY(check_model(m));
   DARK_CHECK_ARG(B > 0 && N > 0 && R >= 0 && R <= B * N, "forward_tail: bad B=%d N=%d rows=%d", B, N, R);
   if (R == 0) return DARK_OK;
@@ -117,17 +121,17 @@ static int forward_tail(const dark_model_desc* m, int B, int N, const int32_t* r
   const int d = m->d, n_src = B * N;
   FwdWs w = carve_fwd(m, (size_t)n_src, (char*)workspace);
   DARK_CHECK_ARG(ws_bytes >= w.total, "forward_tail: workspace %zu < required %zu bytes", ws_bytes, w.total);
-  if (m->n_layers == 0) return launch_gather_rows(m->dtype, nullptr, nullptr, hidden, hidden_rows, rows, n_src, R, d, st);
+  if (m->n_layers == 0) return launch_gather_rows(m->dtype, m->resid_dtype, nullptr, nullptr, hidden, hidden_rows, rows, n_src, R, d, st);
   const dark_layer_weights& L = m->layers[m->n_layers - 1];
   char *att_c = w.xn, *xn_c = w.qkv;
-  DARK_TRY(launch_gather_rows(m->dtype, w.att, att_c, hidden, hidden_rows, rows, n_src, R, d, st));
+  DARK_TRY(launch_gather_rows(m->dtype, m->resid_dtype, w.att, att_c, hidden, hidden_rows, rows, n_src, R, d, st));
   DARK_TRY(resid_gemm_norm(m, att_c, L.w_o, hidden_rows, L.ln2, xn_c, R, d, st));
   DARK_TRY(launch_gemm(m->dtype, EPI_SWIGLU, xn_c, L.w_gu, nullptr, w.act, R, 2 * m->ff, d, m->ff, st));
   DARK_TRY(resid_gemm_norm(m, w.act, L.w_down, hidden_rows, nullptr, nullptr, R, m->ff, st));
   return DARK_OK;
 }
 
-static int lm_head_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int n_src, int M,
+static int lm_head_rows(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int n_src, int M,
                         void* workspace, size_t ws_bytes, float* logits, int64_t ldl, hipStream_t st) {
   DARK_TRY(check_model(m));
   if (M <= 0) return DARK_OK;
@@ -135,7 +139,7 @@ static int lm_head_rows(const dark_model_desc* m, const float* hidden, const int
   DARK_CHECK_ARG(ldl >= m->vocab, "lm_head_rows: ldl=%lld < vocab=%d", (long long)ldl, m->vocab);
   const size_t need = align_up((size_t)M * m->d * esize(m->dtype), 256);
   DARK_CHECK_ARG(ws_bytes >= need, "lm_head_rows: workspace %zu < required %zu bytes", ws_bytes, need);
-  DARK_TRY(launch_rmsnorm(m->dtype, hidden, m->final_norm, workspace, src_rows, n_src, M, m->d, m->rms_eps, st));
+  DARK_TRY(launch_rmsnorm(m->dtype, m->resid_dtype, hidden, m->final_norm, workspace, src_rows, n_src, M, m->d, m->rms_eps, st));
   DARK_TRY(launch_gemm(m->dtype, EPI_F32, workspace, m->lm_head, nullptr, logits, M, m->vocab, m->d, ldl, st));
   return DARK_OK;
 }
@@ -167,13 +171,13 @@ static int scratch_on_current_device(void** out) {
 
 struct StepWs {
   char* fwd;
-  float* hidden;
+  char* hidden;
   int32_t *row_index, *src_rows, *count;
   char* head;
   float* logits;
   float* conf;
   int64_t* x0;
-  float* hidden_rows;
+  char* hidden_rows;
   size_t fwd_bytes, head_bytes, total;
 };
 static StepWs carve_step(const dark_model_desc* m, int B, int N, int M, char* base) {
@@ -183,7 +187,8 @@ static StepWs carve_step(const dark_model_desc* m, int B, int N, int M, char* ba
   const size_t rows = (size_t)B * N;
   w.fwd_bytes = carve_fwd(m, rows, nullptr).total;
   w.fwd = take(w.fwd_bytes);
-  w.hidden = (float*)take(rows * m->d * 4);
+  const size_t hs = esize(m->resid_dtype);   // the residual stream: fp32, or bf16 for bf16 models that ask for it
+  w.hidden = take(rows * m->d * hs);
   w.row_index = (int32_t*)take(rows * 4);
   w.src_rows = (int32_t*)take(rows * 4);
   w.count = (int32_t*)take(16);
@@ -192,7 +197,7 @@ static StepWs carve_step(const dark_model_desc* m, int B, int N, int M, char* ba
   w.logits = (float*)take((size_t)M * m->vocab * 4);
   w.conf = (float*)take((size_t)M * 4);
   w.x0 = (int64_t*)take((size_t)M * 8);
-  w.hidden_rows = (float*)take((size_t)M * m->d * 4);
+  w.hidden_rows = take((size_t)M * m->d * hs);
   w.total = off;
   return w;
 }
@@ -233,22 +238,22 @@ int dark_step_workspace_offsets(const dark_model_desc* m, int B, int N, int M, s
 }
 
 int dark_forward_hidden(const dark_model_desc* m, const int64_t* ids, const int32_t* pos, const uint8_t* key_mask,
-                        int B, int N, void* workspace, size_t workspace_bytes, float* hidden, void* stream) {
+                        int B, int N, void* workspace, size_t workspace_bytes, void* hidden, void* stream) {
   return forward_hidden(m, ids, pos, key_mask, B, N, workspace, workspace_bytes, hidden, (hipStream_t)stream);
 }
 
 int dark_forward_hidden_begin(const dark_model_desc* m, const int64_t* ids, const int32_t* pos,
                               const uint8_t* key_mask, int B, int N, void* workspace, size_t workspace_bytes,
-                              float* hidden, void* stream) {
+                              void* hidden, void* stream) {
   return forward_hidden(m, ids, pos, key_mask, B, N, workspace, workspace_bytes, hidden, (hipStream_t)stream, true);
 }
 
 int dark_forward_hidden_rows(const dark_model_desc* m, int B, int N, const int32_t* rows, int n_rows, void* workspace,
-                             size_t workspace_bytes, const float* hidden, float* hidden_rows, void* stream) {
+                             size_t workspace_bytes, const void* hidden, void* hidden_rows, void* stream) {
   return forward_tail(m, B, N, rows, n_rows, workspace, workspace_bytes, hidden, hidden_rows, (hipStream_t)stream);
 }
 
-int dark_lm_head_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M, void* workspace,
+int dark_lm_head_rows(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int M, void* workspace,
                       size_t workspace_bytes, float* logits, int64_t ldl, void* stream) {
   // src_rows entries are clamped to < 2^30 rows; callers pass indices produced by dark_mask_rows
   return lm_head_rows(m, hidden, src_rows, 1 << 30, M, workspace, workspace_bytes, logits, ldl, (hipStream_t)stream);
@@ -295,7 +300,7 @@ __global__ void head_stats_kernel(const int32_t* counters, int32_t* stats, int M
   if (threadIdx.x == 0 && blockIdx.x == 0) { stats[0] += M; stats[1] += counters[0]; }
 }
 
-static int head_sample_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int n_src, int M,
+static int head_sample_rows(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int n_src, int M,
                             void* workspace, size_t ws_bytes, float* logits, int64_t ldl, float temperature, float top_p,
                             int top_k, int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
                             uint32_t nthreads, float* conf, int64_t* x0, int32_t* stats, hipStream_t st) {
@@ -313,7 +318,7 @@ static int head_sample_rows(const dark_model_desc* m, const float* hidden, const
   DARK_CHECK_ARG(ws_bytes >= w.total, "head_sample_rows: workspace %zu < required %zu bytes", ws_bytes, w.total);
   const int w_rows = cdiv(V, 128) * 128;
   DARK_CHECK_HIP(hipMemsetAsync(w.counters, 0, 16, st));
-  DARK_TRY(launch_rmsnorm(m->dtype, hidden, m->final_norm, w.xn, src_rows, n_src, M, m->d, m->rms_eps, st));
+  DARK_TRY(launch_rmsnorm(m->dtype, m->resid_dtype, hidden, m->final_norm, w.xn, src_rows, n_src, M, m->d, m->rms_eps, st));
   DARK_TRY(launch_gemm_head(w.xn, m->lm_head, w.records, M, V, m->d, head_c2(temperature), head_range_raw(temperature),
                             nullptr, w_rows, st));
   DARK_TRY(launch_head_finish(w.records, w.P, M, V, m->d, w.xn, m->lm_head, temperature, top_p, conf_mode, noise, ldn, seed,
@@ -335,7 +340,7 @@ size_t dark_head_sample_workspace_bytes(const dark_model_desc* m, int M) {
   return carve_head_fuse(m, (size_t)M, nullptr).total;
 }
 
-int dark_head_sample_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M, void* workspace,
+int dark_head_sample_rows(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int M, void* workspace,
                           size_t workspace_bytes, float* logits, int64_t ldl, float temperature, float top_p, int top_k,
                           int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
                           uint32_t nthreads, float* conf, int64_t* x0, int32_t* stats, void* stream) {
@@ -354,7 +359,7 @@ size_t dark_noalloc_max_rows(const dark_model_desc* m) {
   return kNoAllocScratchBytes / ((size_t)m->d * esize(m->dtype));
 }
 
-int dark_lm_head_rows_noalloc(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M,
+int dark_lm_head_rows_noalloc(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int M,
                               float* logits, int64_t ldl, void* stream) {
   DARK_TRY(check_model(m));
   if (M <= 0) return DARK_OK;
@@ -371,12 +376,12 @@ int dark_lm_head_rows_noalloc(const dark_model_desc* m, const float* hidden, con
 }
 
 // ---- vocabulary-sharded head (BASELINE config 3)
-int dark_final_norm_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M, void* out,
+int dark_final_norm_rows(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int M, void* out,
                          void* stream) {
   DARK_TRY(check_model(m));
   if (M <= 0) return DARK_OK;
   DARK_CHECK_ARG(hidden && out, "final_norm_rows: null pointer");
-  return launch_rmsnorm(m->dtype, hidden, m->final_norm, out, src_rows, 1 << 30, M, m->d, m->rms_eps, (hipStream_t)stream);
+  return launch_rmsnorm(m->dtype, m->resid_dtype, hidden, m->final_norm, out, src_rows, 1 << 30, M, m->d, m->rms_eps, (hipStream_t)stream);
 }
 
 int dark_lm_head_shard(const dark_model_desc* m, const void* xn, int M, int v0, int Vs, float* logits, int64_t ldl,
@@ -517,15 +522,15 @@ int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const floa
   DARK_CHECK_ARG(qkv && cosT && sinT && out && B > 0 && H > 0, "dbg_attention: bad argument");
   return launch_attention(dtype, qkv, cosT, sinT, pos, key_mask, out, B, N, H, HD, max_pos, (hipStream_t)stream);
 }
-int dark_dbg_rmsnorm(int dtype, const float* x, const float* w, void* out, const int32_t* src_rows, int n_src, int M,
-                     int d, float eps, void* stream) {
+int dark_dbg_rmsnorm(int dtype, int x_dtype, const void* x, const float* w, void* out, const int32_t* src_rows, int n_src,
+                     int M, int d, float eps, void* stream) {
   DARK_CHECK_ARG(x && w && out, "dbg_rmsnorm: null pointer");
-  return launch_rmsnorm(dtype, x, w, out, src_rows, n_src, M, d, eps, (hipStream_t)stream);
+  return launch_rmsnorm(dtype, x_dtype, x, w, out, src_rows, n_src, M, d, eps, (hipStream_t)stream);
 }
-int dark_dbg_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+int dark_dbg_embed(int dtype, int x_dtype, const int64_t* ids, const void* table, void* out, int M, int d, int vocab,
                    void* stream) {
   DARK_CHECK_ARG(ids && table && out && M > 0, "dbg_embed: bad argument");
-  return launch_embed(dtype, ids, table, out, M, d, vocab, (hipStream_t)stream);
+  return launch_embed(dtype, x_dtype, ids, table, out, M, d, vocab, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -121,6 +121,29 @@ template <> struct ElemTraits<bf16_t> {
   __device__ static __forceinline__ bf16_t from_f32(float v) { return (bf16_t)v; }
 };
 
+// The residual stream is fp32 or, for bf16 models with dark_model_desc.resid_dtype = DARK_BF16, bf16 (what the
+// reference's bf16 model carries: `hidden_states = residual + hidden_states` on bf16 tensors,
+// modeling_dream_length.py:508, :514).  TH = its element type; four consecutive elements move as one access.
+template <typename TH>
+__device__ __forceinline__ float4 load4(const TH* p) {
+  if constexpr (sizeof(TH) == 4) {
+    return *(const float4*)p;
+  } else {
+    const bf16x4 b = *(const bf16x4*)p;
+    return make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
+  }
+}
+template <typename TH>
+__device__ __forceinline__ void store4(TH* p, const float4 v) {
+  if constexpr (sizeof(TH) == 4) {
+    *(float4*)p = v;
+  } else {
+    bf16x4 b;
+    b[0] = (bf16_t)v.x; b[1] = (bf16_t)v.y; b[2] = (bf16_t)v.z; b[3] = (bf16_t)v.w;
+    *(bf16x4*)p = b;
+  }
+}
+
 // XCD-aware, bijective remap of a 1-D block id: blocks b and b+8 share an XCD (round-robin
 // dispatch), so give every XCD one contiguous chunk of the tile space for L2 reuse.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -133,7 +156,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ---- launchers implemented across the .hip files --------------------------
 // GEMM epilogues: C[M,N] = A[M,K] * W[N,K]^T (+...)
 enum Epi { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_F32 = 3, EPI_LSE = 4, EPI_HEAD = 5, EPI_BIAS_GELU = 6,
-           EPI_RESID_BIAS = 7 };
+           EPI_RESID_BIAS = 7, EPI_RESID_H = 8, EPI_RESID_BIAS_H = 9 };
 
 // A: [M,K] dtype, W: [Npad,K] dtype (rows padded to a multiple of 128 with zeros).
 // EPI_BIAS  : out (dtype) [M,ldo] = acc + bias[n]
@@ -142,6 +165,8 @@ enum Epi { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_F32 = 3, EPI_LSE = 4
 // EPI_F32   : out (fp32) [M,ldo] = acc, columns n < N only
 // EPI_BIAS_GELU : out (dtype) [M,ldo] = gelu_new(acc + bias[n])            (GPT-2 backbone: mlp.c_fc + act)
 // EPI_RESID_BIAS: resid (fp32) [M,ldo] += acc + bias[n]                     (GPT-2 backbone: attn / mlp c_proj)
+// EPI_RESID_H / EPI_RESID_BIAS_H: the two residual flavours on a bf16 residual stream (bf16 only):
+//             resid (bf16) [M,ldo] = bf16(float(resid) + acc (+ bias[n])), one rounding
 // EPI_LSE   : bf16 only; bias = int64 targets [M]; out = float2 part[M][ldo] (max, sum exp(acc - max)) per
 //             64-column wave slice, ldo = 2*ceil(N/128), followed by float tgt[M] = acc[m][target[m]]
 int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out,
@@ -181,22 +206,23 @@ int launch_gemm_resid_norm(const void* A, const void* W, float* hidden, const fl
 int prof_select(int epi, int rows = 0);
 int prof_read(double* total_ms, double* total_flops, int* launches);
 
-int launch_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+// `xdt` below = element type of the residual stream: DARK_F32, or DARK_BF16 (bf16 models only)
+int launch_embed(int dtype, int xdt, const int64_t* ids, const void* table, void* out, int M, int d, int vocab,
                  hipStream_t st);
 // out[m] = w * (x[src(m)] * rsqrt(mean(x^2) + eps)); src_rows nullable (identity), else clamped to [0,n_src)
-int launch_embed_norm(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+int launch_embed_norm(int dtype, int xdt, const int64_t* ids, const void* table, void* out, int M, int d, int vocab,
                       const float* ln_w, float eps, void* xn, hipStream_t st);
-int launch_rmsnorm(int dtype, const float* x, const float* w, void* out, const int32_t* src_rows, int n_src,
+int launch_rmsnorm(int dtype, int xdt, const void* x, const float* w, void* out, const int32_t* src_rows, int n_src,
                    int M, int d, float eps, hipStream_t st);
-// att_out[r] = att[rows[r]] (model dtype; both nullable together) and x_out[r] = x[rows[r]] (fp32), rows clamped to
-// [0, n_src)
-int launch_gather_rows(int dtype, const void* att, void* att_out, const float* x, float* x_out, const int32_t* rows,
+// att_out[r] = att[rows[r]] (model dtype; both nullable together) and x_out[r] = x[rows[r]] (stream dtype), rows
+// clamped to [0, n_src)
+int launch_gather_rows(int dtype, int xdt, const void* att, void* att_out, const void* x, void* x_out, const int32_t* rows,
                        int n_src, int R, int d, hipStream_t st);
 int launch_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                      const uint8_t* kmask, void* out, int B, int N, int H, int HD, int max_pos,
                      hipStream_t st, bool causal = false);
 // gpt2.hip: torch.nn.LayerNorm over gathered rows (src_rows nullable = identity, clamped to [0, n_src))
-int launch_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, const int32_t* src_rows,
+int launch_layernorm(int dtype, int xdt, const void* x, const float* w, const float* b, void* out, const int32_t* src_rows,
                      int n_src, int M, int d, float eps, hipStream_t st);
 int launch_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* row_index,
                      int32_t* src_rows, int32_t* count, hipStream_t st);

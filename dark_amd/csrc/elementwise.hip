@@ -5,10 +5,10 @@
 namespace dark {
 
 // ------------------------------------------------------------------ embedding (modeling_dream_length.py:665)
-template <typename TW>
+template <typename TW, typename TH>
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids,
                                                     const TW* __restrict__ table,
-                                                    float* __restrict__ out, int M, int d, int vocab) {
+                                                    TH* __restrict__ out, int M, int d, int vocab) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   int64_t id = ids[row];
@@ -16,25 +16,16 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
   // the table -- nothing validates them on the host, a caller that needs the error checks ids.max() itself
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   const TW* src = table + id * d;
-  float* dst = out + (int64_t)row * d;
-  for (int c = lane * 4; c < d; c += 256) {
-    float4 v;
-    if constexpr (sizeof(TW) == 4) {
-      v = *(const float4*)(src + c);
-    } else {
-      const bf16x4 b = *(const bf16x4*)(src + c);
-      v = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
-    }
-    *(float4*)(dst + c) = v;
-  }
+  TH* dst = out + (int64_t)row * d;
+  for (int c = lane * 4; c < d; c += 256) store4<TH>(dst + c, load4<TW>(src + c));
 }
 
 // Embedding + the first layer's input RMSNorm in one pass (d <= 1024): the gathered row is already in registers, so
 // xn = weight * row / rms(row) costs no second read of the 4*d-byte fp32 row.  Arithmetic and summation order are
 // rmsnorm_kernel's.
-template <typename TW>
+template <typename TW, typename TH>
 __global__ __launch_bounds__(256) void embed_norm_kernel(const int64_t* __restrict__ ids, const TW* __restrict__ table,
-                                                         float* __restrict__ out, const float* __restrict__ w,
+                                                         TH* __restrict__ out, const float* __restrict__ w,
                                                          TW* __restrict__ xn, int M, int d, int vocab, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
@@ -46,14 +37,9 @@ __global__ __launch_bounds__(256) void embed_norm_kernel(const int64_t* __restri
   for (int p = 0; p < 4; ++p) {
     const int c = lane * 4 + p * 256;
     if (c < d) {
-      if constexpr (sizeof(TW) == 4) {
-        v[p] = *(const float4*)(src + c);
-      } else {
-        const bf16x4 b = *(const bf16x4*)(src + c);
-        v[p] = make_float4((float)b[0], (float)b[1], (float)b[2], (float)b[3]);
-      }
+      v[p] = load4<TW>(src + c);
       g[p] = *(const float4*)(w + c);
-      *(float4*)(out + (int64_t)row * d + c) = v[p];
+      store4<TH>(out + (int64_t)row * d + c, v[p]);   // (a bf16 table row is exact in either stream type)
     }
   }
   float ss = 0.f;
@@ -66,52 +52,59 @@ __global__ __launch_bounds__(256) void embed_norm_kernel(const int64_t* __restri
   for (int p = 0; p < 4; ++p) {
     const int c = lane * 4 + p * 256;
     if (c < d) {
-      const float y0 = g[p].x * (v[p].x * r), y1 = g[p].y * (v[p].y * r), y2 = g[p].z * (v[p].z * r),
-                  y3 = g[p].w * (v[p].w * r);
-      if constexpr (sizeof(TW) == 4) {
-        *(float4*)(xn + (int64_t)row * d + c) = make_float4(y0, y1, y2, y3);
-      } else {
-        bf16x4 b;
-        b[0] = (bf16_t)y0; b[1] = (bf16_t)y1; b[2] = (bf16_t)y2; b[3] = (bf16_t)y3;
-        *(bf16x4*)(xn + (int64_t)row * d + c) = b;
-      }
+      store4<TW>(xn + (int64_t)row * d + c,
+                 make_float4(g[p].x * (v[p].x * r), g[p].y * (v[p].y * r), g[p].z * (v[p].z * r), g[p].w * (v[p].w * r)));
     }
   }
 }
 
-int launch_embed_norm(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+// `xdt` = element type of the residual stream (DARK_F32, or DARK_BF16 for a bf16 model)
+static int check_stream_dtype(int dtype, int xdt) {
+  DARK_CHECK_ARG(xdt == DARK_F32 || (xdt == DARK_BF16 && dtype == DARK_BF16),
+                 "residual stream dtype %d does not go with model dtype %d (fp32 always, bf16 for bf16 models)", xdt, dtype);
+  return DARK_OK;
+}
+
+int launch_embed_norm(int dtype, int xdt, const int64_t* ids, const void* table, void* out, int M, int d, int vocab,
                       const float* ln_w, float eps, void* xn, hipStream_t st) {
+  DARK_TRY(check_stream_dtype(dtype, xdt));
   if (d > 1024 || d % 4 != 0) {
-    DARK_TRY(launch_embed(dtype, ids, table, out, M, d, vocab, st));
-    return launch_rmsnorm(dtype, out, ln_w, xn, nullptr, M, M, d, eps, st);
+    DARK_TRY(launch_embed(dtype, xdt, ids, table, out, M, d, vocab, st));
+    return launch_rmsnorm(dtype, xdt, out, ln_w, xn, nullptr, M, M, d, eps, st);
   }
   DARK_CHECK_ARG(ids && table && out && ln_w && xn, "embed_norm: null pointer");
   const dim3 grid(cdiv(M, 4)), block(256);
-  if (dtype == DARK_BF16)
-    hipLaunchKernelGGL(embed_norm_kernel<bf16_t>, grid, block, 0, st, ids, (const bf16_t*)table, out, ln_w, (bf16_t*)xn, M,
-                       d, vocab, eps);
+  if (dtype == DARK_BF16 && xdt == DARK_BF16)
+    hipLaunchKernelGGL((embed_norm_kernel<bf16_t, bf16_t>), grid, block, 0, st, ids, (const bf16_t*)table, (bf16_t*)out, ln_w,
+                       (bf16_t*)xn, M, d, vocab, eps);
+  else if (dtype == DARK_BF16)
+    hipLaunchKernelGGL((embed_norm_kernel<bf16_t, float>), grid, block, 0, st, ids, (const bf16_t*)table, (float*)out, ln_w,
+                       (bf16_t*)xn, M, d, vocab, eps);
   else
-    hipLaunchKernelGGL(embed_norm_kernel<float>, grid, block, 0, st, ids, (const float*)table, out, ln_w, (float*)xn, M, d,
-                       vocab, eps);
+    hipLaunchKernelGGL((embed_norm_kernel<float, float>), grid, block, 0, st, ids, (const float*)table, (float*)out, ln_w,
+                       (float*)xn, M, d, vocab, eps);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }
 
-int launch_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+int launch_embed(int dtype, int xdt, const int64_t* ids, const void* table, void* out, int M, int d, int vocab,
                  hipStream_t st) {
+  DARK_TRY(check_stream_dtype(dtype, xdt));
   DARK_CHECK_ARG(d % 4 == 0, "embed: d=%d must be a multiple of 4", d);
   const dim3 grid(cdiv(M, 4)), block(256);
-  if (dtype == DARK_BF16)
-    hipLaunchKernelGGL(embed_kernel<bf16_t>, grid, block, 0, st, ids, (const bf16_t*)table, out, M, d, vocab);
+  if (dtype == DARK_BF16 && xdt == DARK_BF16)
+    hipLaunchKernelGGL((embed_kernel<bf16_t, bf16_t>), grid, block, 0, st, ids, (const bf16_t*)table, (bf16_t*)out, M, d, vocab);
+  else if (dtype == DARK_BF16)
+    hipLaunchKernelGGL((embed_kernel<bf16_t, float>), grid, block, 0, st, ids, (const bf16_t*)table, (float*)out, M, d, vocab);
   else
-    hipLaunchKernelGGL(embed_kernel<float>, grid, block, 0, st, ids, (const float*)table, out, M, d, vocab);
+    hipLaunchKernelGGL((embed_kernel<float, float>), grid, block, 0, st, ids, (const float*)table, (float*)out, M, d, vocab);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }
 
 // ------------------------------------------------------------------ RMSNorm (modeling_dream_length.py:69-74)
-template <typename TOut>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x,
+template <typename TOut, typename TH>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const TH* __restrict__ x,
                                                       const float* __restrict__ w,
                                                       TOut* __restrict__ out,
                                                       const int32_t* __restrict__ src_rows, int n_src,
@@ -123,17 +116,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     src = src_rows[row];
     src = src < 0 ? 0 : (src >= n_src ? n_src - 1 : src);
   }
-  const float* xr = x + src * d;
+  const TH* xr = x + src * d;
   TOut* o = out + (int64_t)row * d;
   auto emit = [&](int c, const float4 v, const float4 g, float r) {
-    const float y0 = g.x * (v.x * r), y1 = g.y * (v.y * r), y2 = g.z * (v.z * r), y3 = g.w * (v.w * r);
-    if constexpr (sizeof(TOut) == 4) {
-      *(float4*)(o + c) = make_float4(y0, y1, y2, y3);
-    } else {
-      bf16x4 b;
-      b[0] = (bf16_t)y0; b[1] = (bf16_t)y1; b[2] = (bf16_t)y2; b[3] = (bf16_t)y3;
-      *(bf16x4*)(o + c) = b;
-    }
+    store4<TOut>(o + c, make_float4(g.x * (v.x * r), g.y * (v.y * r), g.z * (v.z * r), g.w * (v.w * r)));
   };
   if (d <= 1024) {
     // the row (and the weights) stay in registers between the two passes: one memory round trip per row, not two
@@ -141,7 +127,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int c = lane * 4 + p * 256;
-      if (c < d) { v[p] = *(const float4*)(xr + c); g[p] = *(const float4*)(w + c); }
+      if (c < d) { v[p] = load4<TH>(xr + c); g[p] = *(const float4*)(w + c); }
     }
     float ss = 0.f;
 #pragma unroll
@@ -156,38 +142,46 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   }
   float ss = 0.f;
   for (int c = lane * 4; c < d; c += 256) {
-    const float4 v = *(const float4*)(xr + c);
+    const float4 v = load4<TH>(xr + c);
     ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
   ss = wave_sum(ss);
   const float r = 1.0f / sqrtf(ss / (float)d + eps);
-  for (int c = lane * 4; c < d; c += 256) emit(c, *(const float4*)(xr + c), *(const float4*)(w + c), r);
+  for (int c = lane * 4; c < d; c += 256) emit(c, load4<TH>(xr + c), *(const float4*)(w + c), r);
 }
 
-int launch_rmsnorm(int dtype, const float* x, const float* w, void* out, const int32_t* src_rows, int n_src,
+int launch_rmsnorm(int dtype, int xdt, const void* x, const float* w, void* out, const int32_t* src_rows, int n_src,
                    int M, int d, float eps, hipStream_t st) {
+  DARK_TRY(check_stream_dtype(dtype, xdt));
   DARK_CHECK_ARG(d % 4 == 0, "rmsnorm: d=%d must be a multiple of 4", d);
   if (M <= 0) return DARK_OK;
   const dim3 grid(cdiv(M, 4)), block(256);
-  if (dtype == DARK_BF16)
-    hipLaunchKernelGGL(rmsnorm_kernel<bf16_t>, grid, block, 0, st, x, w, (bf16_t*)out, src_rows, n_src, M, d, eps);
+  if (dtype == DARK_BF16 && xdt == DARK_BF16)
+    hipLaunchKernelGGL((rmsnorm_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)x, w, (bf16_t*)out, src_rows, n_src,
+                       M, d, eps);
+  else if (dtype == DARK_BF16)
+    hipLaunchKernelGGL((rmsnorm_kernel<bf16_t, float>), grid, block, 0, st, (const float*)x, w, (bf16_t*)out, src_rows, n_src, M,
+                       d, eps);
   else
-    hipLaunchKernelGGL(rmsnorm_kernel<float>, grid, block, 0, st, x, w, (float*)out, src_rows, n_src, M, d, eps);
+    hipLaunchKernelGGL((rmsnorm_kernel<float, float>), grid, block, 0, st, (const float*)x, w, (float*)out, src_rows, n_src, M, d,
+                       eps);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }
 
 // ------------------------------------------------------------------ row gather for the last layer's tail
-// One wave per output row: the attention output row (model dtype) and the residual row (fp32) of position rows[r].
-template <typename T>
+// One wave per output row: the attention output row (model dtype) and the residual row (fp32 or bf16) of position
+// rows[r].
+template <typename T, typename TH>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ att, T* __restrict__ att_out,
-                                                          const float* __restrict__ x, float* __restrict__ x_out,
+                                                          const TH* __restrict__ x, TH* __restrict__ x_out,
                                                           const int32_t* __restrict__ rows, int n_src, int R, int d) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= R) return;
   int64_t src = rows[r];
   src = src < 0 ? 0 : (src >= n_src ? n_src - 1 : src);
-  for (int c = lane * 4; c < d; c += 256) *(float4*)(x_out + (int64_t)r * d + c) = *(const float4*)(x + src * d + c);
+  constexpr int EH = 16 / (int)sizeof(TH);
+  for (int c = lane * EH; c < d; c += 64 * EH) *(uint4*)(x_out + (int64_t)r * d + c) = *(const uint4*)(x + src * d + c);
   if (att) {
     constexpr int E = 16 / (int)sizeof(T);  // elements per 16-byte piece
     for (int c = lane * E; c < d; c += 64 * E)
@@ -195,18 +189,22 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
   }
 }
 
-int launch_gather_rows(int dtype, const void* att, void* att_out, const float* x, float* x_out, const int32_t* rows,
+int launch_gather_rows(int dtype, int xdt, const void* att, void* att_out, const void* x, void* x_out, const int32_t* rows,
                        int n_src, int R, int d, hipStream_t st) {
+  DARK_TRY(check_stream_dtype(dtype, xdt));
   DARK_CHECK_ARG(d % 8 == 0, "gather_rows: d=%d must be a multiple of 8", d);
   DARK_CHECK_ARG(x && x_out && rows && (att == nullptr) == (att_out == nullptr), "gather_rows: null pointer");
   if (R <= 0) return DARK_OK;
   const dim3 grid(cdiv(R, 4)), block(256);
-  if (dtype == DARK_BF16)
-    hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)att, (bf16_t*)att_out, x, x_out, rows,
-                       n_src, R, d);
+  if (dtype == DARK_BF16 && xdt == DARK_BF16)
+    hipLaunchKernelGGL((gather_rows_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)att, (bf16_t*)att_out,
+                       (const bf16_t*)x, (bf16_t*)x_out, rows, n_src, R, d);
+  else if (dtype == DARK_BF16)
+    hipLaunchKernelGGL((gather_rows_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)att, (bf16_t*)att_out,
+                       (const float*)x, (float*)x_out, rows, n_src, R, d);
   else
-    hipLaunchKernelGGL(gather_rows_kernel<float>, grid, block, 0, st, (const float*)att, (float*)att_out, x, x_out, rows,
-                       n_src, R, d);
+    hipLaunchKernelGGL((gather_rows_kernel<float, float>), grid, block, 0, st, (const float*)att, (float*)att_out,
+                       (const float*)x, (float*)x_out, rows, n_src, R, d);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }

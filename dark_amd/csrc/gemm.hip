@@ -35,6 +35,8 @@ __device__ __forceinline__ float gelu_new_f(float x) {
 }
 constexpr bool epi_has_bias(int epi) { return epi == EPI_BIAS || epi == EPI_BIAS_GELU; }
 constexpr bool epi_is_resid(int epi) { return epi == EPI_RESID || epi == EPI_RESID_BIAS; }
+// the same two with the residual stream held in bf16 (bf16 models, dark_model_desc.resid_dtype = DARK_BF16)
+constexpr bool epi_is_resid_h(int epi) { return epi == EPI_RESID_H || epi == EPI_RESID_BIAS_H; }
 
 // acc[mi][ni][r]: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 inside a 32x32 tile
 template <int EPI, typename T>
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
     // latency per stage instead of one in front of every group of 8 MFMAs (+4 % on qkv and gate/up).  The residual
     // flavour keeps the compiler's interleaved order: with its prefetched residual pieces the 80 fragment registers
     // would spill.
-    if constexpr (epi_is_resid(EPI)) {
+    if constexpr (epi_is_resid(EPI) || EPI == EPI_RESID_BIAS_H) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int ch = ((4 * ks + fq) ^ fsw) << 4;
@@ -260,10 +262,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
     }
   }
 
+  // bf16 residual stream: the same read-modify-write on 16-byte pieces of EIGHT bf16 values.  A piece is what
+  // store_pair_bf16 writes: for a pair of column tiles (2p, 2p + 1) even 16-lane rows own columns 4q .. 4q+7 of the
+  // first tile, odd rows 4(q-1) .. 4(q-1)+7 of the second; the fp32 accumulators are brought into that layout with one
+  // permlane16_swap per register, the old values are added in fp32 and the sum is rounded once.  12 pieces a lane
+  // (48 registers) instead of 24 (96): half the bytes of the fp32 stream each way.
+  constexpr int TP = TNW / 2;
+  bf16_t* obh = nullptr;
+  uint4 oldh0[2][TP], oldh1[2][TP];
+  const int hcol = (fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq;   // first column of this lane's piece inside a tile pair
+  auto resid_h_ok = [&](int mi, int p) {
+    return m0 + wm * 64 + mi * 16 + frow < M && n0 + wn * WN + 32 * p + hcol + 8 <= N;
+  };
+  if constexpr (epi_is_resid_h(EPI)) {
+    static_assert(TNW % 2 == 0, "bf16 residual epilogue works on pairs of column tiles");
+    if (vec_ok) {
+      obh = (bf16_t*)out + (int64_t)(m0 + wm * 64 + frow) * ldo + n0 + wn * WN + hcol;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int p = 0; p < TP; ++p)
+          if (resid_h_ok(mi, p)) oldh0[mi][p] = *(const uint4*)(obh + (int64_t)mi * 16 * ldo + 32 * p);
+    }
+  }
+
   // Bias flavour: the TNW bias pieces of this lane's columns are fetched here, once, and ride under the first
   // stage's wait; in the epilogue they would be a dependent load in front of every store (24 a lane).
   float4 b4[TNW];
-  if constexpr (epi_has_bias(EPI) || EPI == EPI_RESID_BIAS) {
+  if constexpr (epi_has_bias(EPI) || EPI == EPI_RESID_BIAS || EPI == EPI_RESID_BIAS_H) {
 #pragma unroll
     for (int ni = 0; ni < TNW; ++ni) {
       const int c = n0 + wn * WN + ni * 16 + 4 * fq;
@@ -291,7 +317,48 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
             if (resid_ok(mi, ni)) old1[mi - 2][ni] = *(const float4*)(ob + (int64_t)mi * 16 * ldo + ni * 16);
       }
     }
+    if constexpr (epi_is_resid_h(EPI)) {
+      if (vec_ok && kt == KT - 1) {
+#pragma unroll
+        for (int mi = 2; mi < 4; ++mi)
+#pragma unroll
+          for (int p = 0; p < TP; ++p)
+            if (resid_h_ok(mi, p)) oldh1[mi - 2][p] = *(const uint4*)(obh + (int64_t)mi * 16 * ldo + 32 * p);
+      }
+    }
     compute(kt & 1);
+  }
+
+  // bf16 residual stream, 16-byte path (see the prefetch above the main loop).  The swaps run in every lane.
+  if constexpr (epi_is_resid_h(EPI)) {
+    if (vec_ok) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+          f32x4 a = acc[2 * p][mi], b = acc[2 * p + 1][mi];
+          if constexpr (EPI == EPI_RESID_BIAS_H) {  // hidden + (acc + bias), as the fp32 flavour
+            a[0] += b4[2 * p].x; a[1] += b4[2 * p].y; a[2] += b4[2 * p].z; a[3] += b4[2 * p].w;
+            b[0] += b4[2 * p + 1].x; b[1] += b4[2 * p + 1].y; b[2] += b4[2 * p + 1].z; b[3] += b4[2 * p + 1].w;
+          }
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[e]), __float_as_uint(b[e]), false, false);
+            v[e] = __uint_as_float(sw[0]);
+            v[4 + e] = __uint_as_float(sw[1]);
+          }
+          if (resid_h_ok(mi, p)) {
+            const uint4 o = mi < 2 ? oldh0[mi & 1][p] : oldh1[mi & 1][p];
+            const uint32_t ow[4] = {o.x, o.y, o.z, o.w};
+            uint32_t r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              r[j] = pack_bf16x2(v[2 * j] + __uint_as_float(ow[j] << 16), v[2 * j + 1] + __uint_as_float(ow[j] & 0xffff0000u));
+            *(uint4*)(obh + (int64_t)mi * 16 * ldo + 32 * p) = make_uint4(r[0], r[1], r[2], r[3]);
+          }
+        }
+    }
   }
 
   // Residual flavour, 16-byte path: second half of the read-modify-write (see the prefetch above the main loop).
@@ -390,6 +457,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel16(const bf16_t* __res
             for (int e = 0; e < 4; ++e)
               if (tc == ni * 16 + e) v = acc[ni][mi][e];
           ((float*)((float2*)out + (int64_t)M * ldo))[mrow] = v;
+        }
+      }
+    } else if constexpr (epi_is_resid_h(EPI)) {
+      if (!row_ok || vec_ok) continue;  // (16-byte path: done above, in batches)
+      bf16_t* orow = (bf16_t*)out + mrow * ldo;
+#pragma unroll
+      for (int ni = 0; ni < TNW; ++ni) {
+        const int c = n0 + wn * WN + ni * 16 + 4 * fq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (c + e >= N) continue;
+          float a = acc[ni][mi][e];
+          if constexpr (EPI == EPI_RESID_BIAS_H) a += bias[c + e];
+          orow[c + e] = (bf16_t)((float)orow[c + e] + a);
         }
       }
     } else {
@@ -521,7 +602,7 @@ static int launch_epi(int dtype, const void* A, const void* W, const float* bias
   const int nwg = tilesM * tilesN;
   if (dtype == DARK_BF16) {
     // 16-B row pieces need 16-B aligned rows: bf16 outputs 8 elements, fp32 outputs 4
-    const int per16 = (epi_has_bias(EPI) || EPI == EPI_SWIGLU) ? 8 : 4;
+    const int per16 = (epi_has_bias(EPI) || EPI == EPI_SWIGLU || epi_is_resid_h(EPI)) ? 8 : 4;
     const int ncols = EPI == EPI_SWIGLU ? N / 2 : N;
     const int vec_ok = (ldo % per16 == 0) && (ncols % per16 == 0) &&
                        ((uintptr_t)out % 16 == 0) && (bias == nullptr || (uintptr_t)bias % 16 == 0);
@@ -532,8 +613,8 @@ static int launch_epi(int dtype, const void* A, const void* W, const float* bias
     if constexpr (EPI == EPI_F32 || EPI == EPI_LSE) return launch_k16<EPI, 128>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
     else return launch_k16<EPI, 192>(A, W, bias, out, M, N, K, ldo, vec_ok, st);
   } else {
-    if constexpr (EPI == EPI_LSE) {
-      set_error("gemm: the fused log-sum-exp epilogue exists for bf16 only");
+    if constexpr (EPI == EPI_LSE || epi_is_resid_h(EPI)) {
+      set_error("gemm: epilogue %d exists for bf16 only", EPI);
       return DARK_ERR_UNSUPPORTED;
     } else {
       hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3(nwg), dim3(256), 0, st, (const float*)A,
@@ -661,6 +742,10 @@ static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, co
     case EPI_RESID_BIAS:
       DARK_CHECK_ARG(bias != nullptr, "gemm: EPI_RESID_BIAS needs a bias");
       return launch_epi<EPI_RESID_BIAS>(dtype, A, W, bias, out, M, N, K, ldo, st);
+    case EPI_RESID_H: return launch_epi<EPI_RESID_H>(dtype, A, W, bias, out, M, N, K, ldo, st);
+    case EPI_RESID_BIAS_H:
+      DARK_CHECK_ARG(bias != nullptr, "gemm: EPI_RESID_BIAS_H needs a bias");
+      return launch_epi<EPI_RESID_BIAS_H>(dtype, A, W, bias, out, M, N, K, ldo, st);
     case EPI_SWIGLU:
       DARK_CHECK_ARG(N % 32 == 0, "gemm: SWIGLU needs N %% 32 == 0 (N=%d)", N);
       return launch_epi<EPI_SWIGLU>(dtype, A, W, bias, out, M, N, K, ldo, st);

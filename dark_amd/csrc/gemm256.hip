@@ -696,7 +696,8 @@ static int cu_count(int* cus) {
 // (tools/gemm_ab.py --variants 8,10: its fewer bytes per MAC pay for its four instead of five LDS buffers), so the
 // choice is tile quantisation: the height that needs fewer row-rounds over the CUs.
 static int s256_pick_mi(int epi, int M, int tilesN, int cus) {
-  if (epi == EPI_BIAS) return 8;   // (keeps its bias vector behind four 32-KiB buffers)
+  // (the bias flavour keeps its bias vector behind the K-tile buffers: 320-row tiles leave it 16 KiB)
+  if (epi == EPI_BIAS && tilesN * 256 * 4 > 160 * 1024 - s_smem(EPI_BIAS, 10)) return 8;
   const int forced = g_s256_rows.load(std::memory_order_relaxed);
   if (forced == 256) return 8;
   if (forced == 320) return 10;
@@ -742,7 +743,7 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   else if (probe == 132) DARK_S256_LAUNCH(EPI_SWIGLU, 132, 8, bias, no_mdev, 0.f, 0.f)
   else if (probe == 9) DARK_S256_LAUNCH(EPI_SWIGLU, 8, 10, bias, no_mdev, 0.f, 0.f)   // (per-phase sums of the 320-row tile)
   else if (epi == EPI_SWIGLU) { DARK_S256_EITHER(EPI_SWIGLU, no_mdev, 0.f, 0.f) }
-  else if (epi == EPI_BIAS) DARK_S256_LAUNCH(EPI_BIAS, 0, 8, bias, no_mdev, 0.f, 0.f)
+  else if (epi == EPI_BIAS) { DARK_S256_EITHER(EPI_BIAS, no_mdev, 0.f, 0.f) }
   else { DARK_S256_EITHER(EPI_F32, no_mdev, 0.f, 0.f) }
   DARK_CHECK_LAUNCH();
   return DARK_OK;

@@ -118,7 +118,7 @@ size_t dark_logprob_workspace_bytes(const dark_model_desc* m, int M) {
   return logprob_ws(m, M);
 }
 
-int dark_lm_head_logprob(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int n_src,
+int dark_lm_head_logprob(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int n_src,
                          const int64_t* targets, int M, void* workspace, size_t workspace_bytes, float* logp,
                          void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -129,7 +129,7 @@ int dark_lm_head_logprob(const dark_model_desc* m, const float* hidden, const in
   char* ws = (char*)workspace;
   void* xn = ws;
   ws += align_up((size_t)M * m->d * (m->dtype == DARK_BF16 ? 2 : 4), 256);
-  DARK_TRY(launch_rmsnorm(m->dtype, hidden, m->final_norm, xn, src_rows, n_src, M, m->d, m->rms_eps, st));
+  DARK_TRY(launch_rmsnorm(m->dtype, m->resid_dtype, hidden, m->final_norm, xn, src_rows, n_src, M, m->d, m->rms_eps, st));
   if (m->dtype == DARK_BF16) {
     const int P = 2 * cdiv(m->vocab, 128);
     float2* part = (float2*)ws;

@@ -98,9 +98,11 @@ def _check_supported(cfg) -> None:
 class PackedGpt2Weights:
     """Device-resident, kernel-ready copy of the GPT-2 parameters + the C descriptor that points at it."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], cfg, device: torch.device, dtype: torch.dtype):
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg, device: torch.device, dtype: torch.dtype,
+                 residual_in_fp32: bool = False):
         assert dtype in (torch.float32, torch.bfloat16)
         self.device, self.dtype = device, dtype
+        self.resid_dtype = torch.float32 if (residual_in_fp32 or dtype == torch.float32) else torch.bfloat16
         self.keep: List[torch.Tensor] = []
 
         def dev(t, dt=None):
@@ -132,6 +134,7 @@ class PackedGpt2Weights:
             dtype=_hip.DARK_BF16 if dtype == torch.bfloat16 else _hip.DARK_F32,
             vocab=cfg.vocab_size, vocab_pad=wte.shape[0], d=d, ff=ff, n_layers=L, n_heads=H, head_dim=hd,
             n_positions=cfg.n_positions, ln_eps=float(cfg.layer_norm_epsilon),
+            resid_dtype=_hip.DARK_BF16 if self.resid_dtype == torch.bfloat16 else _hip.DARK_F32,
             wte=dev(wte).data_ptr(), wpe=dev(sd["transformer.wpe.weight"]).data_ptr(),
             lnf_w=dev(sd["transformer.ln_f.weight"], f32).data_ptr(),
             lnf_b=dev(sd["transformer.ln_f.bias"], f32).data_ptr(),
@@ -259,6 +262,7 @@ class DiffusionModel(DreamGenerationMixin, nn.Module):
     EXPAND / DELETE loop of dark_amd.generation_expand_utils)."""
     config_class = GPT2DiffusionConfig
     generation_config_class = DreamGenerationConfig
+    residual_in_fp32 = False   # bf16 models: fp32 residual stream on request (see DreamModel_length.residual_in_fp32)
 
     def __init__(self, config):
         super().__init__()
@@ -344,11 +348,12 @@ class DiffusionModel(DreamGenerationMixin, nn.Module):
     def packed(self) -> PackedGpt2Weights:
         if self.device.type != "cuda":
             raise RuntimeError("dark_amd runs on a HIP device only: move the model with .to('cuda')")
-        key = (str(self.device), self.dtype, tuple(p._version for p in self.parameters()),
+        key = (str(self.device), self.dtype, bool(self.residual_in_fp32), tuple(p._version for p in self.parameters()),
                tuple(p.data_ptr() for p in self.parameters()))
         if self._packed is None or self._packed_key != key:
             dt = torch.bfloat16 if self.dtype == torch.bfloat16 else torch.float32
-            self._packed = PackedGpt2Weights(self.state_dict(), self.config, self.device, dt)
+            self._packed = PackedGpt2Weights(self.state_dict(), self.config, self.device, dt,
+                                             bool(self.residual_in_fp32))
             self._packed_key = key
             self._states.clear()
         return self._packed

@@ -74,9 +74,13 @@ def rope_tables(head_dim: int, theta: float, max_pos: int) -> Tuple[torch.Tensor
 class PackedWeights:
     """Device-resident, kernel-ready copy of the parameters + the C descriptor that points at it."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], cfg: DreamConfig, device: torch.device, dtype: torch.dtype):
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: DreamConfig, device: torch.device, dtype: torch.dtype,
+                 residual_in_fp32: bool = False):
         assert dtype in (torch.float32, torch.bfloat16)
         self.device, self.dtype = device, dtype
+        # element type of the residual stream: the model dtype (what the reference's bf16 model carries,
+        # modeling_dream_length.py:508, :514), or fp32 for a bf16 model on request
+        self.resid_dtype = torch.float32 if (residual_in_fp32 or dtype == torch.float32) else torch.bfloat16
         self.keep: List[torch.Tensor] = []
 
         def dev(t, dt=None):
@@ -113,6 +117,7 @@ class PackedWeights:
             vocab=cfg.vocab_size, vocab_pad=head.shape[0], d=d, ff=ff, n_layers=L,
             n_heads=cfg.num_attention_heads, head_dim=cfg.head_dim, max_pos=self.max_pos,
             rms_eps=float(cfg.rms_norm_eps),
+            resid_dtype=_hip.DARK_BF16 if self.resid_dtype == torch.bfloat16 else _hip.DARK_F32,
             embed=dev(sd["model.embed_tokens.weight"]).data_ptr(),
             final_norm=dev(sd["model.norm.weight"], torch.float32).data_ptr(),
             lm_head=dev(head).data_ptr(),
@@ -133,7 +138,7 @@ class HipState:
         rows = B * N
         self.fwd_bytes = self._workspace_bytes(B, N)
         self.fwd_ws = torch.empty(self.fwd_bytes, dtype=torch.uint8, device=dev)
-        self.hidden = torch.empty((rows, cfg.hidden_size), dtype=torch.float32, device=dev)
+        self.hidden = torch.empty((rows, cfg.hidden_size), dtype=packed.resid_dtype, device=dev)
         self.row_index = torch.zeros(rows, dtype=torch.int32, device=dev)
         self.src_rows = torch.zeros(rows, dtype=torch.int32, device=dev)
         self.count = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -153,7 +158,7 @@ class HipState:
         self._fuse_calls, self._fuse_off_until = 0, 0
         self.conf = torch.empty(rows, dtype=torch.float32, device=dev)
         self.x0 = torch.empty(rows, dtype=torch.int64, device=dev)
-        self.hidden_rows = torch.empty((rows, cfg.hidden_size), dtype=torch.float32, device=dev)
+        self.hidden_rows = torch.empty((rows, cfg.hidden_size), dtype=packed.resid_dtype, device=dev)
         self.hidden_valid = False  # hidden / row_index / count describe the caller's current x
         self.rows_valid = False    # hidden_rows holds the last layer's output for src_rows[:M] of that x
 
@@ -363,6 +368,10 @@ class DreamModel_length(DreamGenerationMixin, nn.Module):
     """modeling_dream_length.py:736-824 (inference surface)."""
     config_class = DreamConfig
     generation_config_class = DreamGenerationConfig
+    # bf16 models: carry the residual stream in fp32 instead of the model dtype (no counterpart in the reference,
+    # whose bf16 model adds bf16 tensors; costs ~5 % of the denoise step, DESIGN.md section 4).  Set on the instance
+    # or the class before the first call; fp32 models always use fp32.
+    residual_in_fp32 = False
 
     def __init__(self, config: DreamConfig):
         super().__init__()
@@ -441,7 +450,7 @@ class DreamModel_length(DreamGenerationMixin, nn.Module):
 
     # ---- packing / device state
     def _weights_key(self):
-        return (str(self.device), self.dtype, tuple(p._version for p in self.parameters()),
+        return (str(self.device), self.dtype, bool(self.residual_in_fp32), tuple(p._version for p in self.parameters()),
                 tuple(p.data_ptr() for p in self.parameters()))
 
     def packed(self) -> PackedWeights:
@@ -450,7 +459,7 @@ class DreamModel_length(DreamGenerationMixin, nn.Module):
         key = self._weights_key()
         if self._packed is None or self._packed_key != key:
             dt = torch.bfloat16 if self.dtype == torch.bfloat16 else torch.float32
-            self._packed = PackedWeights(self.state_dict(), self.config, self.device, dt)
+            self._packed = PackedWeights(self.state_dict(), self.config, self.device, dt, bool(self.residual_in_fp32))
             self._packed_key = key
             self._states.clear()
         return self._packed

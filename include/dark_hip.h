@@ -23,15 +23,15 @@
 extern "C" {
 #endif
 
-#define DARK_HIP_ABI_VERSION 4
+#define DARK_HIP_ABI_VERSION 5
 
 #define DARK_OK 0
 #define DARK_ERR_ARG 1         /* bad shape / pointer / unsupported size */
 #define DARK_ERR_HIP 2         /* a HIP runtime call failed */
 #define DARK_ERR_UNSUPPORTED 3 /* valid request this build has no kernel for */
 
-/* arithmetic type of weights and GEMM/attention operands (accumulation is always fp32,
- * the residual stream and logits are always fp32) */
+/* arithmetic type of weights and GEMM/attention operands (accumulation and logits are always fp32; the residual
+ * stream is fp32 or -- bf16 models only -- bf16, see dark_model_desc.resid_dtype) */
 #define DARK_F32 0
 #define DARK_BF16 1
 
@@ -67,6 +67,10 @@ typedef struct dark_model_desc {
   int32_t head_dim;   /* 64 or 96 */
   int32_t max_pos;    /* rows of the RoPE tables */
   float rms_eps;
+  int32_t resid_dtype; /* element type of the residual stream (`hidden`, `hidden_rows` below): DARK_F32, or DARK_BF16 for a
+                        * bf16 model -- what the reference's bf16 model carries (`residual + hidden_states` on bf16
+                        * tensors, modeling_dream_length.py:508, :514); each residual add is then float(stream) + the
+                        * fp32 accumulator, rounded once */
   const void* embed;        /* [V, d] model dtype (embed_tokens, :615) */
   const float* final_norm;  /* [d] fp32 (model.norm, :620) */
   const void* lm_head;      /* [vocab_pad, d] model dtype, untied (:743) */
@@ -89,10 +93,10 @@ size_t dark_head_workspace_bytes(const dark_model_desc* m, int M);
  *   pos      [B,N] int32 position ids, or NULL for arange(N)            (generation_utils.py:465-466)
  *   key_mask [B,N] uint8 (1 = attend), or NULL for no masking; the pairwise mask is the outer
  *            AND of this vector with itself, fully-masked query rows give 0 (:469-472)
- *   hidden   [B*N, d] fp32 OUT: residual stream after the last layer (pre final norm) */
+ *   hidden   [B*N, d] m->resid_dtype OUT: residual stream after the last layer (pre final norm) */
 int dark_forward_hidden(const dark_model_desc* m, const int64_t* ids, const int32_t* pos,
                         const uint8_t* key_mask, int B, int N, void* workspace, size_t workspace_bytes,
-                        float* hidden, void* stream);
+                        void* hidden, void* stream);
 
 /* The same body in two calls, for loops that only need the rows the sampler reads.  Bidirectional attention needs
  * every position's keys and values in every layer, but the OUTPUT of the last layer is read by nothing except the LM
@@ -101,21 +105,21 @@ int dark_forward_hidden(const dark_model_desc* m, const int64_t* ids, const int3
  *   dark_forward_hidden_begin: everything up to and including the last layer's attention (independent of the rows);
  *     `hidden` then holds the residual stream BEFORE the last layer's o_proj.
  *   dark_forward_hidden_rows: o_proj + residual + RMSNorm + SwiGLU MLP + residual of the last layer for `rows`
- *     [n_rows] int32 only: hidden_rows [n_rows, d] fp32 OUT = the rows hidden[rows[r]] that dark_forward_hidden
+ *     [n_rows] int32 only: hidden_rows [n_rows, d] m->resid_dtype OUT = the rows hidden[rows[r]] that dark_forward_hidden
  *     would have produced, bit for bit.  Same workspace as the begin call (its contents are consumed).
  * Feed hidden_rows to dark_lm_head_rows with src_rows = NULL. */
 int dark_forward_hidden_begin(const dark_model_desc* m, const int64_t* ids, const int32_t* pos,
                               const uint8_t* key_mask, int B, int N, void* workspace, size_t workspace_bytes,
-                              float* hidden, void* stream);
+                              void* hidden, void* stream);
 int dark_forward_hidden_rows(const dark_model_desc* m, int B, int N, const int32_t* rows, int n_rows, void* workspace,
-                             size_t workspace_bytes, const float* hidden, float* hidden_rows, void* stream);
+                             size_t workspace_bytes, const void* hidden, void* hidden_rows, void* stream);
 
 /* Final RMSNorm + LM head on selected rows.  Replaces `self.norm` (:721) and `lm_head` (:809)
  * restricted to the rows the sampler consumes, including the logit shift of
  * generation_utils.py:496 when `src_rows` comes from dark_mask_rows.
  *   src_rows [M] int32 row ids into `hidden`, or NULL for rows 0..M-1
  *   logits   [M, ldl] fp32 OUT (columns >= V untouched) */
-int dark_lm_head_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M,
+int dark_lm_head_rows(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int M,
                       void* workspace, size_t workspace_bytes, float* logits, int64_t ldl, void* stream);
 
 /* Allocation-free variant of dark_lm_head_rows.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
@@ -132,7 +136,7 @@ int dark_lm_head_rows(const dark_model_desc* m, const float* hidden, const int32
 #define DARK_NOALLOC_SCRATCH_BYTES (8u << 20)
 int dark_noalloc_init(void);
 size_t dark_noalloc_max_rows(const dark_model_desc* m);
-int dark_lm_head_rows_noalloc(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M,
+int dark_lm_head_rows_noalloc(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int M,
                               float* logits, int64_t ldl, void* stream);
 
 /* `mask_index = (x == mask_token_id)` + the row-major compaction `logits[mask_index]` uses
@@ -189,7 +193,7 @@ int dark_philox_exponential(uint64_t seed, uint64_t offset, uint32_t nthreads, u
  *     row_ids[i] of the [M, V] problem; noise row, Philox element index and conf / x0 slot are those of row_ids[i]. */
 #define DARK_SHARD_CAND_CAP 16
 #define DARK_SHARD_PART_BYTES 280
-int dark_final_norm_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M, void* out,
+int dark_final_norm_rows(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int M, void* out,
                          void* stream);
 int dark_lm_head_shard(const dark_model_desc* m, const void* xn, int M, int v0, int Vs, float* logits, int64_t ldl,
                        void* stream);
@@ -231,7 +235,7 @@ int dark_scatter_tokens(int64_t* x, int B, int N, const int32_t* row_index, int 
  *   noise [M, V] fp32 or NULL when temperature == 0;  k = number_transfer_tokens of this step
  *   workspace: dark_step_workspace_bytes(m, B, N, M) bytes */
 size_t dark_step_workspace_bytes(const dark_model_desc* m, int B, int N, int M);
-/* Byte offsets inside the step workspace of {hidden fp32 [B*N,d] (the residual stream before the last layer's o_proj
+/* Byte offsets inside the step workspace of {hidden (m->resid_dtype) [B*N,d] (the residual stream before the last layer's o_proj
  * when M > 0: the step evaluates the rest of that layer for the M masked rows only), row_index i32, src_rows i32, count i32,
  * logits fp32 [M,V], conf fp32 [M], x0 i64 [M]} so callers (hooks, parity tests) can read the
  * intermediates that generation_utils.py:495-517 exposes as Python tensors. */
@@ -293,7 +297,7 @@ int dark_expand_commit_edit_sampled(int64_t* x, int B, int N, const int32_t* row
  * bf16 models never materialise the logits (log-sum-exp partials in the GEMM epilogue); fp32 models go through
  * fp32 logits in chunks of 4096 rows.  src_rows NULL = rows 0..M-1; n_src = rows of `hidden`; targets clamp to [0,V). */
 size_t dark_logprob_workspace_bytes(const dark_model_desc* m, int M);
-int dark_lm_head_logprob(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int n_src,
+int dark_lm_head_logprob(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int n_src,
                          const int64_t* targets, int M, void* workspace, size_t workspace_bytes, float* logp,
                          void* stream);
 /* The same second stage on materialised fp32 logits [M, ldl] (selective_log_softmax's inner step, :133-134). */
@@ -365,6 +369,7 @@ typedef struct dark_gpt2_desc {
   int32_t head_dim;     /* 64 or 96 */
   int32_t n_positions;  /* rows of wpe */
   float ln_eps;         /* layer_norm_epsilon */
+  int32_t resid_dtype;  /* residual stream: DARK_F32, or DARK_BF16 for a bf16 model (as dark_model_desc.resid_dtype) */
   const void* wte;      /* [vocab_pad, d] model dtype: token embedding AND the tied LM head (transformer.wte) */
   const void* wpe;      /* [n_positions, d] model dtype (transformer.wpe) */
   const float* lnf_w;   /* transformer.ln_f weight / bias [d] fp32 */
@@ -382,17 +387,17 @@ typedef struct dark_gpt2_desc {
  *            is 0 come out as zeros here -- the reference never reads them: mask_index requires attention_mask == 1)
  *   causal   0 = bidirectional (what the class intends, :34-36), 1 = causal (what transformers' sdpa path computes
  *            whatever the `attn.bias` buffer holds); see gpt2.hip
- *   hidden   [B*N, d] fp32 OUT (pre ln_f).  Workspace: dark_gpt2_forward_workspace_bytes(m, B, N). */
+ *   hidden   [B*N, d] m->resid_dtype OUT (pre ln_f).  Workspace: dark_gpt2_forward_workspace_bytes(m, B, N). */
 size_t dark_gpt2_forward_workspace_bytes(const dark_gpt2_desc* m, int B, int N);
 int dark_gpt2_forward_hidden(const dark_gpt2_desc* m, const int64_t* ids, const int32_t* pos, const uint8_t* key_mask,
-                             int causal, int B, int N, void* workspace, size_t workspace_bytes, float* hidden,
+                             int causal, int B, int N, void* workspace, size_t workspace_bytes, void* hidden,
                              void* stream);
 /* ln_f + the tied LM head (custom_gpt.py:100-103) on selected rows; arguments as dark_lm_head_rows, workspace
  * >= M * d * sizeof(model dtype) rounded up to 256. */
-int dark_gpt2_lm_head_rows(const dark_gpt2_desc* m, const float* hidden, const int32_t* src_rows, int M, void* workspace,
+int dark_gpt2_lm_head_rows(const dark_gpt2_desc* m, const void* hidden, const int32_t* src_rows, int M, void* workspace,
                            size_t workspace_bytes, float* logits, int64_t ldl, void* stream);
-/* test hook: torch.nn.LayerNorm over (gathered) fp32 rows -> model dtype */
-int dark_dbg_layernorm(int dtype, const float* x, const float* w, const float* b, void* out, const int32_t* src_rows,
+/* test hook: torch.nn.LayerNorm over (gathered) rows of the residual stream (x_dtype) -> model dtype */
+int dark_dbg_layernorm(int dtype, int x_dtype, const void* x, const float* w, const float* b, void* out, const int32_t* src_rows,
                        int n_src, int M, int d, float eps, void* stream);
 
 /* ---- unit-test hooks (no counterpart in the reference): launch ONE kernel of the path so that
@@ -401,7 +406,8 @@ int dark_dbg_layernorm(int dtype, const float* x, const float* w, const float* b
  *        gate/up rows, groups of 16 (bf16) / 32 (fp32) (out [M, N/2] model dtype), 3 = plain fp32 store,
  *        4 = bf16 only, log-sum-exp partials: bias = int64 targets [M], out = float2 [M, ldo = 2*ceil(N/128)] then
  *        float [M] target logits; 6 = gelu_new(acc + bias) (out in model dtype), 7 = residual add of acc + bias into
- *        fp32 out (the GPT-2 backbone's c_fc / c_proj).  W has rows padded to 128. */
+ *        fp32 out (the GPT-2 backbone's c_fc / c_proj); 8 / 9 = 1 / 7 on a bf16 residual stream (bf16 only):
+ *        out (bf16) = bf16(float(out) + acc (+ bias)).  W has rows padded to 128. */
 int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                   int N, int K, int64_t ldo, void* stream);
 /* LM head + sampler for the M masked rows in one call, without materialising the logits where that is possible.
@@ -417,7 +423,7 @@ int dark_dbg_gemm(int dtype, int epi, const void* A, const void* W, const float*
  * in dark_sample_rows(_philox).  stats (device int32[2], nullable): [0] += M, [1] += rows that took the fallback.
  * workspace: dark_head_sample_workspace_bytes(m, M) (>= what dark_lm_head_rows needs). */
 size_t dark_head_sample_workspace_bytes(const dark_model_desc* m, int M);
-int dark_head_sample_rows(const dark_model_desc* m, const float* hidden, const int32_t* src_rows, int M, void* workspace,
+int dark_head_sample_rows(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int M, void* workspace,
                           size_t workspace_bytes, float* logits, int64_t ldl, float temperature, float top_p, int top_k,
                           int conf_mode, const float* noise, int64_t ldn, uint64_t seed, uint64_t offset,
                           uint32_t nthreads, float* conf, int64_t* x0, int32_t* stats, void* stream);
@@ -443,9 +449,10 @@ int dark_dbg_set_gemm_variant(int variant);
 int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                        const uint8_t* key_mask, void* out, int B, int N, int H, int HD, int max_pos,
                        void* stream);
-int dark_dbg_rmsnorm(int dtype, const float* x, const float* w, void* out, const int32_t* src_rows,
+/* (x_dtype = element type of the residual-stream operand: DARK_F32, or DARK_BF16 with dtype = DARK_BF16) */
+int dark_dbg_rmsnorm(int dtype, int x_dtype, const void* x, const float* w, void* out, const int32_t* src_rows,
                      int n_src, int M, int d, float eps, void* stream);
-int dark_dbg_embed(int dtype, const int64_t* ids, const void* table, float* out, int M, int d, int vocab,
+int dark_dbg_embed(int dtype, int x_dtype, const int64_t* ids, const void* table, void* out, int M, int d, int vocab,
                    void* stream);
 
 #ifdef __cplusplus

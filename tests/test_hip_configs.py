@@ -277,11 +277,11 @@ def test_forward_rows_equals_full_forward(real, dtype):
         nb = lib.dark_forward_workspace_bytes(pk.ref, B, N)
         ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
         stream = torch.cuda.current_stream().cuda_stream
-        full = torch.empty(B * N, d, device=DEV)
+        full = torch.empty(B * N, d, device=DEV, dtype=pk.resid_dtype)   # (bf16 models carry a bf16 residual stream)
         _hip.check(lib.dark_forward_hidden(pk.ref, _hip.ptr(x), _hip.ptr(pos), _hip.ptr(km), B, N, _hip.ptr(ws), nb,
                                            _hip.ptr(full), stream))
-        part = torch.full((B * N, d), float("nan"), device=DEV)
-        out = torch.full((rows.numel(), d), float("nan"), device=DEV)
+        part = torch.full((B * N, d), float("nan"), device=DEV, dtype=pk.resid_dtype)
+        out = torch.full((rows.numel(), d), float("nan"), device=DEV, dtype=pk.resid_dtype)
         _hip.check(lib.dark_forward_hidden_begin(pk.ref, _hip.ptr(x), _hip.ptr(pos), _hip.ptr(km), B, N, _hip.ptr(ws),
                                                  nb, _hip.ptr(part), stream))
         _hip.check(lib.dark_forward_hidden_rows(pk.ref, B, N, _hip.ptr(rows_d), rows.numel(), _hip.ptr(ws), nb,

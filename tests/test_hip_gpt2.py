@@ -56,13 +56,22 @@ def test_layernorm_kernel(d):
     xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), rows.to(DEV)
     for dt, tdt, tol in ((_hip.DARK_F32, torch.float32, 2e-5), (_hip.DARK_BF16, torch.bfloat16, 2e-2)):
         out = torch.empty(M, d, device=DEV, dtype=tdt)
-        _hip.check(lib.dark_dbg_layernorm(dt, P(xd), P(wd), P(bd), P(out), P(rd), n_src, M, d, 1e-5, S()))
+        _hip.check(lib.dark_dbg_layernorm(dt, _hip.DARK_F32, P(xd), P(wd), P(bd), P(out), P(rd), n_src, M, d, 1e-5, S()))
         err = (out.cpu().double() - want).abs().max().item()
         assert err <= tol * max(1.0, want.abs().max().item()), (d, dt, err)
     out = torch.empty(n_src, d, device=DEV)   # identity row map
-    _hip.check(lib.dark_dbg_layernorm(_hip.DARK_F32, P(xd), P(wd), P(bd), P(out), None, n_src, n_src, d, 1e-5, S()))
+    _hip.check(lib.dark_dbg_layernorm(_hip.DARK_F32, _hip.DARK_F32, P(xd), P(wd), P(bd), P(out), None, n_src, n_src, d, 1e-5,
+                                      S()))
     full = torch.nn.functional.layer_norm(x.double(), (d,), w.double(), b.double(), 1e-5)
     assert (out.cpu().double() - full).abs().max().item() <= 2e-5 * full.abs().max().item()
+    # a bf16 residual stream: the same rows held in bf16 and in fp32 normalise to the same bf16 values
+    xh = xd.bfloat16()
+    xf = xh.float()
+    o_h = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    o_f = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
+    _hip.check(lib.dark_dbg_layernorm(_hip.DARK_BF16, _hip.DARK_BF16, P(xh), P(wd), P(bd), P(o_h), P(rd), n_src, M, d, 1e-5, S()))
+    _hip.check(lib.dark_dbg_layernorm(_hip.DARK_BF16, _hip.DARK_F32, P(xf), P(wd), P(bd), P(o_f), P(rd), n_src, M, d, 1e-5, S()))
+    assert torch.equal(o_h, o_f)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 512, 128), (777, 768, 3072), (130, 3072, 768), (45, 200, 64)])
@@ -88,6 +97,12 @@ def test_gelu_and_bias_residual_epilogues(M, N, K):
         want = base.double() + acc
         err = (res.cpu().double() - want).abs().max().item()
         assert err <= (2e-5 if dt == _hip.DARK_F32 else 2e-3) * max(1.0, want.abs().max().item()), ("resid", dt, err)
+        if dt == _hip.DARK_BF16:   # the same epilogue on a bf16 residual stream (epi 9): the fp32 result, rounded once
+            hb = base.bfloat16().to(DEV)
+            hf = hb.float()
+            _hip.check(lib.dark_dbg_gemm(dt, 9, P(Ad), P(Wd), P(bd), P(hb), M, N, K, N, S()))
+            _hip.check(lib.dark_dbg_gemm(dt, 7, P(Ad), P(Wd), P(bd), P(hf), M, N, K, N, S()))
+            assert torch.equal(hb, hf.bfloat16())
 
 
 # ----------------------------------------------------------------------------------------------- forward

@@ -95,7 +95,7 @@ def test_fused_logprob_equals_unfused(vocab):
     pk = m.packed()
     g = torch.Generator().manual_seed(0)
     R, M = 300, 517
-    hidden = (torch.randn(R, 192, generator=g) * 3).to(DEV)
+    hidden = (torch.randn(R, 192, generator=g) * 3).to(DEV).to(pk.resid_dtype)   # (the model's residual-stream dtype)
     src = torch.randint(0, R, (M,), generator=g).int().to(DEV)
     targets = torch.randint(0, vocab, (M,), generator=g)
     targets[:4] = torch.tensor([0, vocab - 1, 127, 128])

@@ -116,7 +116,7 @@ def test_gemm_rowpanel_resid_norm(lib, M, K):
     x2 = torch.full((M, d), 3.0, device=DEV, dtype=torch.bfloat16)
     H.check(lib.dark_dbg_gemm_resid_norm(H.ptr(A), H.ptr(W), H.ptr(h1), H.ptr(gam), H.ptr(x1), M, K, eps, _s()))
     H.check(lib.dark_dbg_gemm(H.DARK_BF16, 1, H.ptr(A), H.ptr(W), None, H.ptr(h2), M, d, K, d, _s()))
-    H.check(lib.dark_dbg_rmsnorm(H.DARK_BF16, H.ptr(h2), H.ptr(gam), H.ptr(x2), None, M, M, d, eps, _s()))
+    H.check(lib.dark_dbg_rmsnorm(H.DARK_BF16, H.DARK_F32, H.ptr(h2), H.ptr(gam), H.ptr(x2), None, M, M, d, eps, _s()))
     h3 = h0.clone()
     H.check(lib.dark_dbg_gemm_resid_norm(H.ptr(A), H.ptr(W), H.ptr(h3), None, None, M, K, eps, _s()))
     torch.cuda.synchronize()
@@ -141,7 +141,7 @@ def test_embed_and_rmsnorm(lib, dtype):
     ids = torch.randint(0, V, (M,), generator=g)
     out = torch.zeros(M, d, device=DEV)
     idd, tabd = ids.to(DEV), table.to(DEV)
-    H.check(lib.dark_dbg_embed(_dt(dtype), H.ptr(idd), H.ptr(tabd), H.ptr(out), M, d, V, _s()))
+    H.check(lib.dark_dbg_embed(_dt(dtype), H.DARK_F32, H.ptr(idd), H.ptr(tabd), H.ptr(out), M, d, V, _s()))
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), table.float()[ids])
     x = torch.randn(M, d, generator=g) * 3
@@ -149,11 +149,60 @@ def test_embed_and_rmsnorm(lib, dtype):
     src = torch.randint(0, M, (40,), generator=g).int()
     y = torch.zeros(40, d, device=DEV, dtype=dtype)
     xd, wd, srcd = x.to(DEV), w.to(DEV), src.to(DEV)
-    H.check(lib.dark_dbg_rmsnorm(_dt(dtype), H.ptr(xd), H.ptr(wd), H.ptr(y), H.ptr(srcd), M, 40, d, 1e-6, _s()))
+    H.check(lib.dark_dbg_rmsnorm(_dt(dtype), H.DARK_F32, H.ptr(xd), H.ptr(wd), H.ptr(y), H.ptr(srcd), M, 40, d, 1e-6, _s()))
     torch.cuda.synchronize()
     ref = O.rms_norm(x[src.long()], w, 1e-6)
     np.testing.assert_allclose(y.cpu().float().numpy(), ref.numpy(), **(_tol(dtype) if dtype == torch.bfloat16
                                                                          else dict(rtol=2e-6, atol=1e-6)))
+    # a bf16 residual stream exists for bf16 models only
+    assert lib.dark_dbg_rmsnorm(H.DARK_F32, H.DARK_BF16, H.ptr(xd), H.ptr(wd), H.ptr(y), None, M, 40, d, 1e-6, _s()) \
+        == H.DARK_ERR_ARG
+
+
+def test_bf16_residual_stream_kernels(lib):
+    """The elementwise kernels on a bf16 residual stream (dark_model_desc.resid_dtype = DARK_BF16): the embedding copies
+    the bf16 table rows exactly; RMSNorm of a bf16 stream == RMSNorm of the same values held in fp32, bit for bit."""
+    H = _hip()
+    g = torch.Generator().manual_seed(5)
+    V, d, M = 512, 768, 203
+    table = torch.randn(V, d, generator=g).bfloat16()
+    ids = torch.randint(0, V, (M,), generator=g)
+    out = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+    idd, tabd = ids.to(DEV), table.to(DEV)
+    H.check(lib.dark_dbg_embed(H.DARK_BF16, H.DARK_BF16, H.ptr(idd), H.ptr(tabd), H.ptr(out), M, d, V, _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), table[ids])
+    x = (torch.randn(M, d, generator=g) * 3).bfloat16().to(DEV)
+    w = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    src = torch.randint(0, M, (90,), generator=g).int().to(DEV)
+    y_h = torch.zeros(90, d, device=DEV, dtype=torch.bfloat16)
+    y_f = torch.zeros(90, d, device=DEV, dtype=torch.bfloat16)
+    xf = x.float()
+    H.check(lib.dark_dbg_rmsnorm(H.DARK_BF16, H.DARK_BF16, H.ptr(x), H.ptr(w), H.ptr(y_h), H.ptr(src), M, 90, d, 1e-6, _s()))
+    H.check(lib.dark_dbg_rmsnorm(H.DARK_BF16, H.DARK_F32, H.ptr(xf), H.ptr(w), H.ptr(y_f), H.ptr(src), M, 90, d, 1e-6, _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(y_h, y_f)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (777, 768, 3072), (130, 384, 128), (45, 200, 64), (2049, 768, 192)])
+def test_gemm_bf16_residual_epilogue(lib, M, N, K):
+    """EPI_RESID_H (epi 8): out (bf16) = bf16(float(out) + A W^T), ONE rounding of the fp32 sum -- compared with the
+    fp32-stream flavour (epi 1) started from the same values: rounding its fp32 result gives the bf16 result bit for
+    bit (same accumulators, same add).  Rows beyond M stay untouched; unaligned N takes the scalar tail."""
+    H = _hip()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    W = torch.zeros((N + 127) // 128 * 128, K, dtype=torch.bfloat16)
+    W[:N] = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    W = W.to(DEV)
+    h0 = torch.randn(M + 3, N, generator=g).bfloat16().to(DEV)
+    hb, hf = h0.clone(), h0.float()
+    H.check(lib.dark_dbg_gemm(H.DARK_BF16, 8, H.ptr(A), H.ptr(W), None, H.ptr(hb), M, N, K, N, _s()))
+    H.check(lib.dark_dbg_gemm(H.DARK_BF16, 1, H.ptr(A), H.ptr(W), None, H.ptr(hf), M, N, K, N, _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(hb[:M], hf[:M].bfloat16())
+    assert torch.equal(hb[M:], h0[M:]), "rows beyond M must stay untouched"
+    assert lib.dark_dbg_gemm(H.DARK_F32, 8, H.ptr(hf), H.ptr(hf), None, H.ptr(hf), M, N, K, N, _s()) == H.DARK_ERR_UNSUPPORTED
 
 
 # --------------------------------------------------------------------------- attention

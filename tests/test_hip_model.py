@@ -256,6 +256,27 @@ def test_bf16_decisions_close_to_fp32(golden_meta):
     assert close >= 0.95, close
 
 
+def test_bf16_residual_stream_modes(golden_meta):
+    """bf16 models carry the residual stream in bf16 by default (what the reference's bf16 model does,
+    modeling_dream_length.py:508, :514) and in fp32 with `residual_in_fp32 = True`.  Both against the fp32 model of the
+    same weights at the real width: each within the stated bf16 bound (3 % of the logit range), and the bf16 stream
+    within 2x the error of the fp32 stream (the other bf16 roundings -- operands, activations -- dominate)."""
+    kw = dict(golden_meta["real"], num_hidden_layers=4)
+    ids = torch.nn.functional.pad(synth.make_inputs(16, "ded", seed=4), (0, 1), value=synth.MASK).to(DEV)
+    ref = _model(kw, False, torch.float32)(ids).logits.float().cpu()
+    errs = {}
+    for fp32_stream in (False, True):
+        m = _model(kw, False, torch.bfloat16)
+        m.residual_in_fp32 = fp32_stream
+        got = m(ids).logits.float().cpu()
+        assert m.packed().resid_dtype == (torch.float32 if fp32_stream else torch.bfloat16)
+        errs[fp32_stream] = ((got - ref).abs().max() / ref.abs().max()).item()
+        del m
+    print(f"bf16 logits vs fp32, max error / logit range: bf16 stream {errs[False]:.4f}, fp32 stream {errs[True]:.4f}")
+    assert errs[False] < 3e-2 and errs[True] < 3e-2, errs
+    assert errs[False] < 2.0 * errs[True] + 1e-3, errs
+
+
 def test_api_contract(mini, goldens):
     ids = torch.from_numpy(goldens["loop_abd_ids"]).to(DEV)
     before = ids.clone()

@@ -34,7 +34,8 @@ def main():
     st = _hip.stream_ptr(dev)
     g = torch.Generator().manual_seed(0)
     shapes = [("gate/up swiglu", 2, 6144, 768), ("qkv+bias", 0, 2304, 768), ("lm_head f32", 3, 15080, 768),
-              ("gate/up K3072", 2, 6144, 3072), ("o_proj resid", 1, 768, 768), ("down resid", 1, 768, 3072)]
+              ("gate/up K3072", 2, 6144, 3072), ("o_proj resid", 1, 768, 768), ("down resid", 1, 768, 3072),
+              ("o_proj resid bf16", 8, 768, 768), ("down resid bf16", 8, 768, 3072)]   # (bf16 residual stream)
     for name, epi, N, K in shapes:
         if args.only and args.only not in name:
             continue
@@ -54,13 +55,15 @@ def main():
                 ldo, odt = N // 2, torch.bfloat16
             else:
                 ldo, odt = N, torch.float32
-            base = torch.randn(M, ldo, generator=g) if epi == 1 else None   # the residual stream the GEMM adds to
-            if epi == 1:
+            base = torch.randn(M, ldo, generator=g) if epi in (1, 8) else None   # the residual stream the GEMM adds to
+            if epi == 8:
+                base, odt = base.bfloat16(), torch.bfloat16
+            if base is not None:
                 ref = ref + base.double()
             outs = []
             for v in variants:
                 _hip.check(lib.dark_dbg_set_gemm_variant(v))
-                out = base.to(dev).clone() if epi == 1 else torch.full((M, ldo), float("nan"), device=dev, dtype=odt)
+                out = base.to(dev).clone() if base is not None else torch.full((M, ldo), float("nan"), device=dev, dtype=odt)
                 _hip.check(lib.dark_dbg_gemm(1, epi, _hip.ptr(Ad), _hip.ptr(Wd), _hip.ptr(bd) if epi == 0 else None,
                                              _hip.ptr(out), M, N, K, ldo, st))
                 torch.cuda.synchronize()
@@ -77,6 +80,8 @@ def main():
         bd = torch.randn(Wt.shape[0], device=dev)
         ldo = N // 2 if epi == 2 else N
         o = torch.zeros(M, ldo, device=dev, dtype=torch.float32 if epi in (1, 3) else torch.bfloat16)
+        if epi == 8:
+            A = A * 0.01   # (the in-place sums of thousands of timing launches must stay finite in bf16)
         bptr = _hip.ptr(bd) if epi == 0 else None
         times = {v: [] for v in variants}
         for r in range(args.rounds + 1):

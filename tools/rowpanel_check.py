@@ -22,7 +22,7 @@ def both(lib, st, A, W, h0, g):
     x2 = torch.full_like(x1, float("nan"))
     _hip.check(lib.dark_dbg_gemm_resid_norm(_hip.ptr(A), _hip.ptr(W), _hip.ptr(h1), _hip.ptr(g), _hip.ptr(x1), M, K, EPS, st))
     _hip.check(lib.dark_dbg_gemm(BF16, EPI_RESID, _hip.ptr(A), _hip.ptr(W), None, _hip.ptr(h2), M, D, K, D, st))
-    _hip.check(lib.dark_dbg_rmsnorm(BF16, _hip.ptr(h2), _hip.ptr(g), _hip.ptr(x2), None, M, M, D, EPS, st))
+    _hip.check(lib.dark_dbg_rmsnorm(BF16, 0, _hip.ptr(h2), _hip.ptr(g), _hip.ptr(x2), None, M, M, D, EPS, st))
     torch.cuda.synchronize()
     return h1, x1, h2, x2
 
@@ -78,7 +78,7 @@ def main():
 
         def two():
             lib.dark_dbg_gemm(BF16, EPI_RESID, _hip.ptr(A), _hip.ptr(W), None, _hip.ptr(h), M, D, K, D, st)
-            lib.dark_dbg_rmsnorm(BF16, _hip.ptr(h), _hip.ptr(g), _hip.ptr(x), None, M, M, D, EPS, st)
+            lib.dark_dbg_rmsnorm(BF16, 0, _hip.ptr(h), _hip.ptr(g), _hip.ptr(x), None, M, M, D, EPS, st)
 
         def gemm_only():
             lib.dark_dbg_gemm(BF16, EPI_RESID, _hip.ptr(A), _hip.ptr(W), None, _hip.ptr(h), M, D, K, D, st)
