@@ -150,11 +150,61 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const TH* __restrict__ x,
   for (int c = lane * 4; c < d; c += 256) emit(c, load4<TH>(xr + c), *(const float4*)(w + c), r);
 }
 
+// bf16 stream -> bf16 rows, d <= 1024 and d % 8 == 0: HALF a wave per row, 16-byte accesses on both sides (the
+// one-wave-per-row kernel above moves 8 bytes a lane when the stream is bf16: 5.4 TB/s against 6.7 with fp32 input).
+// Same arithmetic per element; the sum of squares is reduced over 32 lanes x 8-element chunks instead of 64 x 4, so
+// the two kernels can differ by one bf16 ulp.
+__global__ __launch_bounds__(256) void rmsnorm_h16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                          bf16_t* __restrict__ out, const int32_t* __restrict__ src_rows,
+                                                          int n_src, int M, int d, float eps) {
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+  if (row >= M) return;   // (whole half-waves leave: the shuffles below stay inside a half)
+  int64_t src = row;
+  if (src_rows) {
+    src = src_rows[row];
+    src = src < 0 ? 0 : (src >= n_src ? n_src - 1 : src);
+  }
+  const bf16_t* xr = x + src * d;
+  bf16x8 v[4];
+  float ss = 0.f;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int c = l * 8 + p * 256;
+    if (c < d) {
+      v[p] = *(const bf16x8*)(xr + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += (float)v[p][e] * (float)v[p][e];
+    }
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float r = 1.0f / sqrtf(ss / (float)d + eps);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int c = l * 8 + p * 256;
+    if (c < d) {
+      const float4 g0 = *(const float4*)(w + c), g1 = *(const float4*)(w + c + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      bf16x8 y;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (bf16_t)(g[e] * ((float)v[p][e] * r));
+      *(bf16x8*)(out + (int64_t)row * d + c) = y;
+    }
+  }
+}
+
 int launch_rmsnorm(int dtype, int xdt, const void* x, const float* w, void* out, const int32_t* src_rows, int n_src,
                    int M, int d, float eps, hipStream_t st) {
   DARK_TRY(check_stream_dtype(dtype, xdt));
   DARK_CHECK_ARG(d % 4 == 0, "rmsnorm: d=%d must be a multiple of 4", d);
   if (M <= 0) return DARK_OK;
+  if (dtype == DARK_BF16 && xdt == DARK_BF16 && d <= 1024 && d % 8 == 0 &&
+      (((uintptr_t)x | (uintptr_t)out | (uintptr_t)w) & 15) == 0) {
+    hipLaunchKernelGGL(rmsnorm_h16_kernel, dim3(cdiv(M, 8)), dim3(256), 0, st, (const bf16_t*)x, w, (bf16_t*)out, src_rows,
+                       n_src, M, d, eps);
+    DARK_CHECK_LAUNCH();
+    return DARK_OK;
+  }
   const dim3 grid(cdiv(M, 4)), block(256);
   if (dtype == DARK_BF16 && xdt == DARK_BF16)
     hipLaunchKernelGGL((rmsnorm_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)x, w, (bf16_t*)out, src_rows, n_src,

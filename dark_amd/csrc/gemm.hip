@@ -688,14 +688,15 @@ int gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 void set_p256_nodma(int v);
 void set_s256_probe(int v);
 void set_s256_rows(int v);
+double s256_best_cost(int epi, int M, int N);
 // 3 = timing probe: variant 2 with the main loop's LDS-DMA issue removed (wrong results); 16 + p = timing probe p of
 // gemm_bf16_s256 (gemm256.hip, wrong results): variant 4 with parts of its intervals removed; 8 / 10 = variant 4 with
-// its tile height forced to 256 / 320 rows (A/B of the two instantiations; other values leave the choice automatic)
+// its tile height forced to 256 / 288 / 320 rows (A/B of the instantiations; other values leave the choice automatic)
 void set_gemm_variant(int v) {
   set_p256_nodma(v == 3);
   set_s256_probe(v >= 16 ? v - 16 : 0);
-  set_s256_rows(v == 8 ? 256 : (v == 10 ? 320 : 0));
-  g_gemm_variant.store(v == 3 ? 2 : ((v >= 16 || v == 8 || v == 10) ? 4 : v), std::memory_order_relaxed);
+  set_s256_rows(v == 8 ? 256 : (v == 9 ? 288 : (v == 10 ? 320 : 0)));
+  g_gemm_variant.store(v == 3 ? 2 : ((v >= 16 || (v >= 8 && v <= 10)) ? 4 : v), std::memory_order_relaxed);
 }
 
 // Which kernel serves a bf16 GEMM: 0 = the 128-row kernels of this file, 2 = gemm_bf16_p256, 4 = gemm_bf16_s256.
@@ -708,13 +709,26 @@ void set_gemm_variant(int v) {
 static int pick_kernel(int dtype, int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias) {
   if (dtype != DARK_BF16) return 0;
   int v = g_gemm_variant.load(std::memory_order_relaxed);
-  if (v == 5) v = 0;  // 5 = automatic GEMM choice + the row-panel kernel for o_proj / down_proj (api.hip)
+  // 6 / 7 = A/B of the automatic choice itself: 6 = without the one-round down_proj routing below, 7 = with q/k/v on
+  // the 288-row persistent kernel as well
+  const bool no_resid_s256 = v == 6, qkv_s256 = v == 7, oproj_s256 = v == 11;   // (11 = o_proj there too)
+  if (v == 5 || v == 6 || v == 7 || v == 11) v = 0;  // 5 = automatic GEMM choice + the row-panel kernel for o_proj / down_proj (api.hip)
   if (v == 1) return 0;
   const bool p_ok = p256_supports(epi, M, N, K, ldo, out, bias), s_ok = s256_supports(epi, M, N, K, ldo, out, bias);
   if (v == 2) return p_ok ? 2 : 0;
   if (v == 4) return s_ok ? 4 : 0;
   const bool enough_tiles = (int64_t)cdiv(M, 256) * cdiv(N, 256) >= 512;
   if (s_ok && enough_tiles && (epi == EPI_F32 || epi == EPI_SWIGLU)) return 4;
+  // down_proj on a bf16 residual stream (N = 768, K = 3072): 736 tiles of 128 x 192 are 1.44 rounds of the 512
+  // workgroup slots, 246 tiles of 288 x 256 are ONE 96 %-full round of the persistent kernel.  Costs in row-rounds of
+  // 256 columns per CU (a round of the 128-row kernel = two 128 x 192 tiles per CU); the 128-row kernel's partial
+  // rounds run faster than the model says (a lone workgroup has the CU to itself), hence the 10 % margin.  Measured
+  // (tools/gemm_ab.py, M = 23552): 110 -> 88 us.  At K = 768 the one-round launch has no next tile to hide its
+  // prologue and epilogue behind and gains nothing (o_proj stays here).
+  if (s_ok && ((epi == EPI_RESID_H && (K >= 1536 || oproj_s256) && !no_resid_s256) || (epi == EPI_BIAS && qkv_s256))) {
+    const double c128 = (double)cdiv(cdiv(M, 128) * cdiv(N, 192), 512) * 192.0;
+    if (s256_best_cost(epi, M, N) * 1.1 < c128) return 4;
+  }
   return 0;
 }
 

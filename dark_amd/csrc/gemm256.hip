@@ -283,6 +283,7 @@ template <> struct StoresPerTile<EPI_SWIGLU> { static constexpr int PER_MI = 1; 
 template <> struct StoresPerTile<EPI_BIAS> { static constexpr int PER_MI = 2; };
 template <> struct StoresPerTile<EPI_F32> { static constexpr int PER_MI = 4; };
 template <> struct StoresPerTile<EPI_HEAD> { static constexpr int PER_MI = 1; };
+template <> struct StoresPerTile<EPI_RESID_H> { static constexpr int PER_MI = 2; };
 constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }  // vmcnt(n), nothing else
 }  // namespace
 
@@ -304,11 +305,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   constexpr int S_OPER = s_aoper(MI), S_BUF = s_buf(MI);
   constexpr int S_SMEM = NB * S_BUF;
   // DMA pieces (16 rows x 64 B, one wave-instruction each) of a K-tile: 2 * MI of A, 16 of W.  Every wave brings two W
-  // pieces; the A pieces go NA0 to each wave of group 0 and NA1 to each wave of group 1 (MI = 8: 2 + 2, MI = 10: 3 + 2),
-  // so the two groups issue different numbers of DMAs per batch and carry their own counted waits.
-  constexpr int NA1 = (2 * MI) / 8, NA0 = (2 * MI - 4 * NA1) / 4;
-  static_assert(4 * NA0 + 4 * NA1 == 2 * MI && NA0 >= NA1, "A pieces do not divide over the waves");
-  constexpr int OPS0 = NA0 + 2, OPS1 = NA1 + 2;          // DMAs per batch of a wave in group 0 / 1
+  // pieces and NALO A pieces; the first NHI waves bring one A piece more (MI = 8: none, MI = 9: waves 0 and 1, MI = 10:
+  // the four waves of group 0), so "hi" and "lo" waves issue different numbers of DMAs per batch and carry their own
+  // counted waits.
+  constexpr int NALO = (2 * MI) / 8, NHI = 2 * MI - 8 * NALO;
+  static_assert(NHI >= 0 && NHI < 8 && NHI * (NALO + 1) + (8 - NHI) * NALO == 2 * MI, "A pieces do not divide over the waves");
+  constexpr int OPSHI = NALO + 3, OPSLO = NALO + 2;      // DMAs per batch of a hi / lo wave
   if (m_dev) {  // row count from device memory (never more than the host's M, which sized the buffers)
     const int md = __builtin_amdgcn_readfirstlane(*m_dev);
     M = md < M ? (md > 0 ? md : 0) : M;
@@ -329,19 +331,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   const unsigned kb = (unsigned)K * 2u;
   // piece = 16 rows x 64 B: lane l -> row (l >> 2), position l & 3 holds logical chunk (l & 3) ^ ((l >> 4) & 2)
   const unsigned voff = (unsigned)(lane >> 2) * kb + (unsigned)(((lane & 3) ^ ((lane >> 4) & 2)) << 4);
-  // this wave's pieces of K-tile kt: A pieces first (NA0 / NA1 of them), then its two W pieces
-  const int pa0 = grp == 0 ? wave * NA0 : 4 * NA0 + (wave - 4) * NA1;   // first A piece of this wave
+  // this wave's pieces of K-tile kt: A pieces first (NALO, or NALO + 1 for a hi wave), then its two W pieces
+  const bool hi = wave < NHI;   // (wave-uniform)
+  const int pa0 = hi ? wave * (NALO + 1) : NHI * (NALO + 1) + (wave - NHI) * NALO;   // first A piece of this wave
   auto stage = [&](int buf, unsigned a0, unsigned w0, int kt) {
     char* base = smem + buf * S_BUF;
-    if constexpr (NA0 != NA1) {
-      if (grp == 0) {  // the extra A piece of group 0's waves
-        const int p = pa0 + NA1;
+    if constexpr (NHI > 0) {
+      if (hi) {  // the extra A piece of the hi waves
+        const int p = pa0 + NALO;
         const unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + p * 1024), 16, voff + (a0 + so), 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int q = 0; q < NA1; ++q) {
+    for (int q = 0; q < NALO; ++q) {
       const int p = pa0 + q;
       const unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + p * 1024), 16, voff + (a0 + so), 0, 0, 0);
@@ -402,8 +405,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   for (int i = 0; i < NB - 1; ++i) stage_next();
   probe_warm = true;
   // K-tile 0 has landed (this wave's pieces): NB - 2 younger batches are still in flight
-  if (OPS0 == OPS1 || grp == 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS1 * (NB - 2)));
-  else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS0 * (NB - 2)));
+  if (NHI == 0 || !hi) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSLO * (NB - 2)));
+  else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSHI * (NB - 2)));
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one interval behind group 0
 
@@ -421,6 +424,53 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
 #pragma unroll
         for (int i = 0; i < MI; ++i) sacc += acc[j][i][0] + acc[j][i][1] + acc[j][i][2] + acc[j][i][3];
       if (sacc == 12345.678f) __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){0u, 0u, 0u, 0u}, ro, 0u, 0, 0);
+      return;
+    }
+    if constexpr (EPI == EPI_RESID_H) {
+      // bf16 residual stream: out = bf16(float(out) + acc), one rounding (gemm.hip EPI_RESID_H).  The old values are
+      // fetched in two batches of 16-byte pieces (the accumulators leave room for half of them), each batch waited
+      // for in full -- every older DMA has then landed too, so the counted waits behind the epilogue stay valid --
+      // and written back in the store layout of the bias flavour: NST buffer stores a wave, out-of-range ones dropped.
+      const int hcol = (fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq;
+      constexpr int HB = (MI + 1) / 2;
+#pragma unroll
+      for (int h0 = 0; h0 < MI; h0 += HB) {
+        u32x4_t old[HB][2];
+        unsigned offs[HB][2];
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+          const int mi = h0 + i;
+          if (mi >= MI) break;
+          const int m = m0 + grp * GROWS + mi * 16 + frow;
+#pragma unroll
+          for (int np = 0; np < 2; ++np) {
+            const int c = n0 + wn * 64 + np * 32 + hcol;
+            offs[i][np] = (m < M && c + 8 <= N) ? (unsigned)(((int64_t)m * ldo + c) * 2) : 0xF0000000u;
+            old[i][np] = __builtin_amdgcn_raw_buffer_load_b128(ro, offs[i][np], 0, 0);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+          const int mi = h0 + i;
+          if (mi >= MI) break;
+#pragma unroll
+          for (int np = 0; np < 2; ++np) {
+            const f32x4 a = acc[2 * np][mi], b = acc[2 * np + 1][mi];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[e]), __float_as_uint(b[e]), false, false);
+              v[e] = __uint_as_float(sw[0]);
+              v[4 + e] = __uint_as_float(sw[1]);
+            }
+            u32x4_t r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              r[j] = pk_bf16(v[2 * j] + __uint_as_float(old[i][np][j] << 16), v[2 * j + 1] + __uint_as_float(old[i][np][j] & 0xffff0000u));
+            __builtin_amdgcn_raw_buffer_store_b128(r, ro, offs[i][np], 0, 0);
+          }
+        }
+      }
       return;
     }
 #pragma unroll
@@ -562,12 +612,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: the fragment reads have returned
         t1 = now();
       }
-      if (OPS0 == OPS1 || grp == 1) {
-        if (pending && kt < NB - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS1 * (NB - 2) + NST) & 0xF0FF);  // + lgkmcnt(0)
-        else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS1 * (NB - 2)) & 0xF0FF);
+      if (NHI == 0 || !hi) {
+        if (pending && kt < NB - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSLO * (NB - 2) + NST) & 0xF0FF);  // + lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSLO * (NB - 2)) & 0xF0FF);
       } else {
-        if (pending && kt < NB - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS0 * (NB - 2) + NST) & 0xF0FF);
-        else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPS0 * (NB - 2)) & 0xF0FF);
+        if (pending && kt < NB - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSHI * (NB - 2) + NST) & 0xF0FF);
+        else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSHI * (NB - 2)) & 0xF0FF);
       }
       if constexpr (PROBE & 8) t2 = now();
       __builtin_amdgcn_s_barrier();
@@ -622,7 +672,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
 
 // Can this shape go to the persistent 256-wide kernel?  (16-byte output pieces, K tiles of 64, 32-bit buffer sizes.)
 bool p256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias) {
-  if (epi != EPI_SWIGLU && epi != EPI_BIAS && epi != EPI_F32) return false;
+  if (epi != EPI_SWIGLU && epi != EPI_BIAS && epi != EPI_F32 && epi != EPI_RESID_H) return false;
   if (K % 64 != 0 || K < 128) return false;
   const int per16 = epi == EPI_F32 ? 4 : 8;
   const int ncols = epi == EPI_SWIGLU ? N / 2 : N;
@@ -637,7 +687,7 @@ void set_p256_nodma(int v) { g_p256_nodma.store(v); }
 
 int launch_gemm_p256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                      int64_t ldo, int w_rows, hipStream_t st) {
-  DARK_CHECK_ARG(p256_supports(epi, M, N, K, ldo, out, bias), "gemm_p256: unsupported shape M=%d N=%d K=%d", M, N, K);
+  DARK_CHECK_ARG(epi != EPI_RESID_H && p256_supports(epi, M, N, K, ldo, out, bias), "gemm_p256: unsupported shape M=%d N=%d K=%d", M, N, K);
   const int tilesM = cdiv(M, PBM), tilesN = cdiv(N, PBN);
   const int ntiles = tilesM * tilesN;
   int dev = 0, cus = 256;
@@ -682,7 +732,7 @@ bool s256_supports(int epi, int M, int N, int K, int64_t ldo, const void* out, c
 
 static std::atomic<int> g_s256_probe{0};
 void set_s256_probe(int v) { g_s256_probe.store(v); }
-static std::atomic<int> g_s256_rows{0};   // 0 = automatic, 256 / 320 = forced tile height (A/B hook)
+static std::atomic<int> g_s256_rows{0};   // 0 = automatic, 256 / 288 / 320 = forced tile height (A/B hook)
 void set_s256_rows(int v) { g_s256_rows.store(v); }
 
 static int cu_count(int* cus) {
@@ -692,18 +742,31 @@ static int cu_count(int* cus) {
   return DARK_OK;
 }
 
-// 16-row MFMA tiles per wave: 8 (256 x 256 tile) or 10 (320 x 256).  Per row the two run at the same rate within 2 %
-// (tools/gemm_ab.py --variants 8,10: its fewer bytes per MAC pay for its four instead of five LDS buffers), so the
-// choice is tile quantisation: the height that needs fewer row-rounds over the CUs.
+// 16-row MFMA tiles per wave: 8 (256 x 256 tile), 9 (288 x 256) or 10 (320 x 256).  Per row the heights run at the
+// same rate within 2 % (tools/gemm_ab.py --variants 8,10: the fewer bytes per MAC of the taller tiles pay for their four
+// instead of five LDS buffers), so the choice is tile quantisation: the height that needs the fewest row-rounds over
+// the CUs (M = 23552: gate/up 7 rounds of 320; q/k/v 3 rounds of 288; N = 768 one round of 246 tiles of 288).
+static double s256_cost(int mi, int M, int tilesN, int cus) {
+  return (double)cdiv(cdiv(M, 32 * mi) * tilesN, cus) * mi * (mi > 8 ? 0.98 : 1.0);
+}
 static int s256_pick_mi(int epi, int M, int tilesN, int cus) {
-  // (the bias flavour keeps its bias vector behind the K-tile buffers: 320-row tiles leave it 16 KiB)
+  // (the bias flavour keeps its bias vector behind the K-tile buffers: the taller tiles leave it 16 KiB)
   if (epi == EPI_BIAS && tilesN * 256 * 4 > 160 * 1024 - s_smem(EPI_BIAS, 10)) return 8;
   const int forced = g_s256_rows.load(std::memory_order_relaxed);
   if (forced == 256) return 8;
+  if (forced == 288) return 9;
   if (forced == 320) return 10;
-  const double c8 = (double)cdiv(cdiv(M, 256) * tilesN, cus) * 8.0;
-  const double c10 = (double)cdiv(cdiv(M, 320) * tilesN, cus) * 10.0 * 0.98;
-  return c10 < c8 ? 10 : 8;
+  int best = 8;
+  for (int mi = 9; mi <= 10; ++mi)
+    if (s256_cost(mi, M, tilesN, cus) < s256_cost(best, M, tilesN, cus)) best = mi;
+  return best;
+}
+// what the automatic choice would cost, in row-rounds (pick_kernel of gemm.hip compares flavours with it)
+double s256_best_cost(int epi, int M, int N) {
+  int cus = 256;
+  const int tilesN = cdiv(N, 256);
+  const int mi = s256_pick_mi(epi, M, tilesN, cus);
+  return s256_cost(mi, M, tilesN, cus) * 32.0;
 }
 
 // one launch of gemm_bf16_s256<E, PB, MI_> with everything the kernel derives from the tile height
@@ -719,6 +782,7 @@ static int s256_pick_mi(int epi, int M, int tilesN, int cus) {
   }
 #define DARK_S256_EITHER(E, MDEV, C2, RANGE)                                \
   if (mi == 10) DARK_S256_LAUNCH(E, 0, 10, bias, MDEV, C2, RANGE)           \
+  else if (mi == 9) DARK_S256_LAUNCH(E, 0, 9, bias, MDEV, C2, RANGE)        \
   else DARK_S256_LAUNCH(E, 0, 8, bias, MDEV, C2, RANGE)
 
 int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
@@ -744,6 +808,7 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   else if (probe == 9) DARK_S256_LAUNCH(EPI_SWIGLU, 8, 10, bias, no_mdev, 0.f, 0.f)   // (per-phase sums of the 320-row tile)
   else if (epi == EPI_SWIGLU) { DARK_S256_EITHER(EPI_SWIGLU, no_mdev, 0.f, 0.f) }
   else if (epi == EPI_BIAS) { DARK_S256_EITHER(EPI_BIAS, no_mdev, 0.f, 0.f) }
+  else if (epi == EPI_RESID_H) { DARK_S256_EITHER(EPI_RESID_H, no_mdev, 0.f, 0.f) }
   else { DARK_S256_EITHER(EPI_F32, no_mdev, 0.f, 0.f) }
   DARK_CHECK_LAUNCH();
   return DARK_OK;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the bf16 GEMM kernels in ONE process (interleaved rounds, same device, random operands): variant 1 = the
 128-row kernels of gemm.hip, 2 = the persistent 256 x 256 kernel of gemm256.hip, 4 = its staggered form with the
-automatic tile height, 8 / 10 = the staggered form with 256 / 320-row tiles (a variant serves the shapes it supports and
+automatic tile height, 8 / 9 / 10 = the staggered form with 256 / 288 / 320-row tiles (a variant serves the shapes it supports and
 falls back to variant 1 elsewhere).  Checks variant 2 against an
 fp64 reference on ragged row counts first.  Usage (GPU box): python tools/gemm_ab.py [--rows 23552] [--rounds 5]"""
 import argparse
@@ -35,7 +35,8 @@ def main():
     g = torch.Generator().manual_seed(0)
     shapes = [("gate/up swiglu", 2, 6144, 768), ("qkv+bias", 0, 2304, 768), ("lm_head f32", 3, 15080, 768),
               ("gate/up K3072", 2, 6144, 3072), ("o_proj resid", 1, 768, 768), ("down resid", 1, 768, 3072),
-              ("o_proj resid bf16", 8, 768, 768), ("down resid bf16", 8, 768, 3072)]   # (bf16 residual stream)
+              ("o_proj resid bf16", 8, 768, 768), ("down resid bf16", 8, 768, 3072),   # (bf16 residual stream)
+              ("n768 k768 bias", 0, 768, 768), ("n768 k3072 bias", 0, 768, 3072)]      # (one-round probes for s256)
     for name, epi, N, K in shapes:
         if args.only and args.only not in name:
             continue
