@@ -1067,12 +1067,26 @@ __global__ __launch_bounds__(256) void head_finish_kernel(const HeadSliceRec* __
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const bf16_t* wrow = W + (int64_t)(p * 64 + frow) * K + fq * 8;
-      for (int kt = 0; kt < K / 32; ++kt) {
-        const bf16x8 fa = *(const bf16x8*)(arow + kt * 32);
+      // K-steps in groups of four: the 20 fragment loads of a group are in flight together (as a loop over single
+      // K-steps every MFMA waited out a round trip to L2: 24 dependent latencies a slice, 84 us a row); the MFMA chain of
+      // each accumulator still runs over ascending k, so the bits are the GEMM's
+      constexpr int HU = 4;
+      const int KT = K / 32;
+      for (int kt0 = 0; kt0 < KT; kt0 += HU) {
+        bf16x8 fa[HU], fw[HU][4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const bf16x8 fw = *(const bf16x8*)(wrow + (int64_t)ni * 16 * K + kt * 32);
-          acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fa, acc[ni], 0, 0, 0);
+        for (int u = 0; u < HU; ++u) {
+          const int kt = min(kt0 + u, KT - 1);   // (a clamped duplicate load instead of a branch; not accumulated)
+          fa[u] = *(const bf16x8*)(arow + kt * 32);
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) fw[u][ni] = *(const bf16x8*)(wrow + (int64_t)ni * 16 * K + kt * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+          if (kt0 + u < KT) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[u][ni], fa[u], acc[ni], 0, 0, 0);
+          }
         }
       }
       // lane (frow, fq) holds columns 64 p + 16 ni + 4 fq + e of row `frow` of the tile (= this row); lanes with

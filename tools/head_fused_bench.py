@@ -17,10 +17,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=16896)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--peaks", default="1,3,6,12")
     a = ap.parse_args()
     dev = torch.device("cuda")
     B = (a.rows + 45) // 46
-    for peak in (1.0, 3.0, 6.0, 12.0):
+    for peak in [float(v) for v in a.peaks.split(',')]:
         cfg = DreamConfig(vocab_size=15080, num_hidden_layers=1, mask_token_id=synth.MASK, pad_token_id=synth.END)
         sd = synth.make_weights(cfg, seed=0)
         sd["model.norm.weight"] = sd["model.norm.weight"] * peak
