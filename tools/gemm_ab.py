@@ -36,7 +36,8 @@ def main():
     shapes = [("gate/up swiglu", 2, 6144, 768), ("qkv+bias", 0, 2304, 768), ("lm_head f32", 3, 15080, 768),
               ("gate/up K3072", 2, 6144, 3072), ("o_proj resid", 1, 768, 768), ("down resid", 1, 768, 3072),
               ("o_proj resid bf16", 8, 768, 768), ("down resid bf16", 8, 768, 3072),   # (bf16 residual stream)
-              ("n768 k768 bias", 0, 768, 768), ("n768 k3072 bias", 0, 768, 3072)]      # (one-round probes for s256)
+              ("n768 k768 bias", 0, 768, 768), ("n768 k3072 bias", 0, 768, 3072),      # (one-round probes for s256)
+              ("probe bias N6144", 0, 6144, 768), ("probe swiglu N2304", 2, 2304, 768)]  # (flavour vs round count)
     for name, epi, N, K in shapes:
         if args.only and args.only not in name:
             continue
