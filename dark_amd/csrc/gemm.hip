@@ -688,7 +688,7 @@ int gemm_variant() { return g_gemm_variant.load(std::memory_order_relaxed); }
 void set_p256_nodma(int v);
 void set_s256_probe(int v);
 void set_s256_rows(int v);
-double s256_best_cost(int epi, int M, int N);
+double s256_best_cost(int epi, int M, int N, int* cus_out);
 // 3 = timing probe: variant 2 with the main loop's LDS-DMA issue removed (wrong results); 16 + p = timing probe p of
 // gemm_bf16_s256 (gemm256.hip, wrong results): variant 4 with parts of its intervals removed; 8 / 10 = variant 4 with
 // its tile height forced to 256 / 288 / 320 rows (A/B of the instantiations; other values leave the choice automatic)
@@ -726,8 +726,10 @@ static int pick_kernel(int dtype, int epi, int M, int N, int K, int64_t ldo, con
   // (tools/gemm_ab.py, M = 23552): 110 -> 88 us.  At K = 768 the one-round launch has no next tile to hide its
   // prologue and epilogue behind and gains nothing (o_proj stays here).
   if (s_ok && ((epi == EPI_RESID_H && (K >= 1536 || oproj_s256) && !no_resid_s256) || (epi == EPI_BIAS && qkv_s256))) {
-    const double c128 = (double)cdiv(cdiv(M, 128) * cdiv(N, 192), 512) * 192.0;
-    if (s256_best_cost(epi, M, N) * 1.1 < c128) return 4;
+    int cus = 256;
+    const double c256 = s256_best_cost(epi, M, N, &cus);
+    const double c128 = (double)cdiv(cdiv(M, 128) * cdiv(N, 192), 2 * cus) * 192.0;   // two workgroups per CU
+    if (c256 * 1.1 < c128) return 4;
   }
   return 0;
 }

@@ -735,10 +735,17 @@ void set_s256_probe(int v) { g_s256_probe.store(v); }
 static std::atomic<int> g_s256_rows{0};   // 0 = automatic, 256 / 288 / 320 = forced tile height (A/B hook)
 void set_s256_rows(int v) { g_s256_rows.store(v); }
 
-static int cu_count(int* cus) {
+static int cu_count(int* cus) {   // CUs of the current device (cached per device: this sits on every launch path)
+  static std::atomic<int> cache[DARK_MAX_DEVICES] = {};
   int dev = 0;
   DARK_CHECK_HIP(hipGetDevice(&dev));
-  DARK_CHECK_HIP(hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const bool cached = dev >= 0 && dev < DARK_MAX_DEVICES;
+  int n = cached ? cache[dev].load(std::memory_order_relaxed) : 0;
+  if (n == 0) {
+    DARK_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cached) cache[dev].store(n, std::memory_order_relaxed);
+  }
+  *cus = n;
   return DARK_OK;
 }
 
@@ -762,8 +769,10 @@ static int s256_pick_mi(int epi, int M, int tilesN, int cus) {
   return best;
 }
 // what the automatic choice would cost, in row-rounds (pick_kernel of gemm.hip compares flavours with it)
-double s256_best_cost(int epi, int M, int N) {
+double s256_best_cost(int epi, int M, int N, int* cus_out) {
   int cus = 256;
+  if (cu_count(&cus) != DARK_OK || cus <= 0) cus = 256;   // (the launch itself reports a HIP error properly)
+  if (cus_out) *cus_out = cus;
   const int tilesN = cdiv(N, 256);
   const int mi = s256_pick_mi(epi, M, tilesN, cus);
   return s256_cost(mi, M, tilesN, cus) * 32.0;

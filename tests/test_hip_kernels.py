@@ -236,7 +236,8 @@ def test_bf16_residual_stream_kernels(lib):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (777, 768, 3072), (130, 384, 128), (45, 200, 64), (2049, 768, 192)])
+@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (777, 768, 3072), (130, 384, 128), (45, 200, 64), (2049, 768, 192),
+                                   (77, 196, 128)])
 def test_gemm_bf16_residual_epilogue(lib, M, N, K):
     """EPI_RESID_H (epi 8): out (bf16) = bf16(float(out) + A W^T), ONE rounding of the fp32 sum -- compared with the
     fp32-stream flavour (epi 1) started from the same values: rounding its fp32 result gives the bf16 result bit for
