@@ -7,8 +7,10 @@
 // identically.  Kernels of this file:
 //   bf16: gemm_bf16_kernel16<EPI, BNt> -- 128 x BNt block tile (BNt = 192, or 128 for the fp32-out flavours), 4 waves
 //         (2 x 2) of v_mfma_f32_16x16x32_bf16 tiles, BK = 64, two LDS stages filled by LDS-DMA, two workgroups per CU.
-//         Serves q/k/v + bias, o_proj / down_proj + residual, the log-sum-exp head of the GRPO path, and every launch
-//         too small for the persistent 256 x 256 kernels of gemm256.hip (pick_kernel below decides).
+//         Serves q/k/v + bias, o_proj + residual (and down_proj + residual where the persistent kernel does not take
+//         it: fp32 residual stream, few rows), the log-sum-exp head of the GRPO path, the GPT-2 epilogues, and every
+//         launch too small for the persistent 256-wide kernels of gemm256.hip (pick_kernel below decides).  The
+//         residual flavours exist for an fp32 stream (EPI_RESID, EPI_RESID_BIAS) and for a bf16 one (.._H).
 //   fp32: gemm_f32_kernel<EPI> -- 128 x 128 tile, 4 waves of 2 x 2 v_mfma_f32_32x32x2_f32 tiles (an exact fp32 fma chain
 //         per output, k ascending: what the bit-exact parity tests against the CPU oracle rely on), BK = 16, LDS rows
 //         padded to 17 floats, register-staged double buffering.
