@@ -442,9 +442,16 @@ int dark_dbg_gemm_head(const void* A, const void* W, void* records, int M, int N
  * DreamRMSNorm of modeling_dream_length.py:384/:451/:69-74 (attention) and :222/:458 (MLP). */
 int dark_dbg_gemm_resid_norm(const void* A, const void* W, float* hidden, const float* ln_w, void* xn, int M, int K,
                              float eps, void* stream);
-/* Which bf16 GEMM kernel dark_dbg_gemm and the forward use: 0 = the library's choice per shape, 1 = always the
- * 128-row kernels (and the residual GEMM + norm as two launches), 2 = the persistent 256 x 256 kernel wherever it supports the shape, 4 = its staggered two-group
- * form, 5 = the library's choice + the row-panel kernel for the residual projections, 3 = timing probe (variant 2 without its main-loop LDS-DMA: wrong results).  A/B measurements and tests. */
+/* Which bf16 GEMM kernel dark_dbg_gemm and the forward use (A/B measurements and tests):
+ *   0 = the library's choice per shape;
+ *   1 = always the 128-row kernels of gemm.hip (and the unfused head);
+ *   2 = the persistent 256 x 256 kernel wherever it supports the shape; 3 = timing probe of it (WRONG results);
+ *   4 = its staggered two-group form (gemm_bf16_s256) wherever it supports the shape, automatic tile height;
+ *   8 / 9 / 10 = the same with the tile height forced to 256 / 288 / 320 rows;
+ *   5 = the library's choice + the row-panel kernel for the residual projections (fp32 residual stream only);
+ *   6 / 7 / 11 = the library's choice without its one-round down_proj routing / with q/k/v / with o_proj on the
+ *   persistent kernel as well (the in-loop A/Bs recorded in DESIGN.md);
+ *   16 + p = timing probe p of gemm_bf16_s256 (WRONG results unless p = 8 or 9: per-phase cycle sums). */
 int dark_dbg_set_gemm_variant(int variant);
 int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                        const uint8_t* key_mask, void* out, int B, int N, int H, int HD, int max_pos,
