@@ -100,7 +100,8 @@ def test_gemm_resid_and_swiglu(lib, dtype):
 
 
 @pytest.mark.parametrize("epi,M,N,K", [(8, 24001, 1536, 192), (8, 777, 768, 3072), (8, 23552, 768, 256),
-                                       (0, 24001, 2304, 128), (2, 5000, 6144, 768), (3, 2049, 15080, 768)])
+                                       (0, 24001, 2304, 128), (2, 5000, 6144, 768), (3, 2049, 15080, 768),
+                                       (8, 1, 768, 128), (0, 288, 512, 128), (2, 289, 512, 128), (3, 321, 264, 128)])
 def test_gemm_persistent_tile_heights_bit_identical(lib, epi, M, N, K):
     """gemm_bf16_s256 (gemm256.hip) with its tile height forced to 256 / 288 / 320 rows (variants 8 / 9 / 10: different
     DMA piece splits and counted waits per height) against the 128-row kernel (variant 1) on the same operands:
