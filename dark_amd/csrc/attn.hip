@@ -253,12 +253,13 @@ int launch_attention(int dtype, const void* qkv, const float* cosT, const float*
   DARK_CHECK_ARG(HD == 64 || HD == 96, "attention: head_dim=%d must be 64 or 96", HD);
   DARK_CHECK_ARG(max_pos >= 1, "attention: empty RoPE table");
   // 16-token tiles: 3 (N <= 48, the default max_length 46: one wave per query tile, 30 KB of LDS -> 5 workgroups
-  // per CU; 38.9 vs 42.0 us at B = 512 against the 4-tile / 4-wave instance), 4 (N <= 64) or 8 (N <= 128, two query
-  // tiles per wave)
+  // per CU; 38.9 vs 42.0 us at B = 512 against the 4-tile / 4-wave instance), 4 (N <= 64) or 8 (N <= 128: 55 KB of
+  // LDS -> 2 workgroups per CU, so one wave per query tile -- 8 waves -- to have 16 instead of 8 waves per CU hiding
+  // the staging latency: BASELINE config 4, 906 -> 923 sequences/s against two query tiles per wave)
 #define DARK_ATTN(T, HDv)                                                                                        \
   if (N <= 48) return launch_attn_t<T, HDv, 3, 3>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0);        \
   if (N <= 64) return launch_attn_t<T, HDv, 4, 4>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0);        \
-  return launch_attn_t<T, HDv, 8, 4>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0)
+  return launch_attn_t<T, HDv, 8, 8>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0)
   if (dtype == DARK_BF16) {
     if (HD == 96) { DARK_ATTN(bf16_t, 96); } else { DARK_ATTN(bf16_t, 64); }
   } else {
