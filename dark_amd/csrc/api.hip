@@ -53,8 +53,8 @@ static FwdWs carve_fwd(const dark_model_desc* m, size_t rows, char* base) {
 }
 
 // hidden += A * W^T (o_proj / down_proj), then -- when `ln` is given -- xn = RMSNorm(hidden) * ln for the next
-// projection: the residual GEMM and the norm as two launches.  Variant 5 (dark_dbg_set_gemm_variant) routes bf16
-// models of width 768 through the row-panel kernel that does both from one set of registers (gemm_rowpanel.hip);
+// projection: the residual GEMM and the norm as two launches (the GEMM flavour follows the residual stream's dtype).
+// Variant 5 (dark_dbg_set_gemm_variant) routes bf16 models of width 768 WITH AN FP32 STREAM through the row-panel kernel that does both from one set of registers (gemm_rowpanel.hip);
 // it is NOT the default: measured in the denoise loop it is 6 % slower end to end (2675 vs 2835 sequences/s,
 // profiles/r02q_rowpanel_ab.txt) -- its 246 workgroups run in lockstep, so the 180 MB residual read-modify-write of all
 // epilogues hits HBM at once with no MFMA work left to hide it, where the multi-round 128 x 192 kernel overlaps
