@@ -43,7 +43,7 @@ static FwdWs carve_fwd(const dark_model_desc* m, size_t rows, char* base) {
   const size_t es = esize(m->dtype);
   FwdWs w;
   size_t off = 0;
-  auto take = [&](size_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };  // (null base: sizes only)
   w.xn = take(rows * m->d * es);
   w.qkv = take(rows * 3 * m->d * es);
   w.att = take(rows * m->d * es);
@@ -178,26 +178,36 @@ struct StepWs {
   float* conf;
   int64_t* x0;
   char* hidden_rows;
+  size_t off[7];   // byte offsets of {hidden, row_index, src_rows, count, logits, conf, x0} (dark_step_workspace_offsets)
   size_t fwd_bytes, head_bytes, total;
 };
 static StepWs carve_step(const dark_model_desc* m, int B, int N, int M, char* base) {
   StepWs w;
   size_t off = 0;
-  auto take = [&](size_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
+  // (offsets first, pointers from them: `base` may be null when only sizes / offsets are wanted)
+  auto take_off = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
+  auto at = [&](size_t o) { return base ? base + o : nullptr; };
   const size_t rows = (size_t)B * N;
   w.fwd_bytes = carve_fwd(m, rows, nullptr).total;
-  w.fwd = take(w.fwd_bytes);
+  w.fwd = at(take_off(w.fwd_bytes));
   const size_t hs = esize(m->resid_dtype);   // the residual stream: fp32, or bf16 for bf16 models that ask for it
-  w.hidden = take(rows * m->d * hs);
-  w.row_index = (int32_t*)take(rows * 4);
-  w.src_rows = (int32_t*)take(rows * 4);
-  w.count = (int32_t*)take(16);
+  w.off[0] = take_off(rows * m->d * hs);
+  w.off[1] = take_off(rows * 4);
+  w.off[2] = take_off(rows * 4);
+  w.off[3] = take_off(16);
   w.head_bytes = align_up((size_t)M * m->d * esize(m->dtype), 256);
-  w.head = take(w.head_bytes);
-  w.logits = (float*)take((size_t)M * m->vocab * 4);
-  w.conf = (float*)take((size_t)M * 4);
-  w.x0 = (int64_t*)take((size_t)M * 8);
-  w.hidden_rows = take((size_t)M * m->d * hs);
+  w.head = at(take_off(w.head_bytes));
+  w.off[4] = take_off((size_t)M * m->vocab * 4);
+  w.off[5] = take_off((size_t)M * 4);
+  w.off[6] = take_off((size_t)M * 8);
+  w.hidden = at(w.off[0]);
+  w.row_index = (int32_t*)at(w.off[1]);
+  w.src_rows = (int32_t*)at(w.off[2]);
+  w.count = (int32_t*)at(w.off[3]);
+  w.logits = (float*)at(w.off[4]);
+  w.conf = (float*)at(w.off[5]);
+  w.x0 = (int64_t*)at(w.off[6]);
+  w.hidden_rows = at(take_off((size_t)M * m->d * hs));
   w.total = off;
   return w;
 }
@@ -227,13 +237,7 @@ size_t dark_step_workspace_bytes(const dark_model_desc* m, int B, int N, int M) 
 int dark_step_workspace_offsets(const dark_model_desc* m, int B, int N, int M, size_t* out7) {
   DARK_CHECK_ARG(m && out7 && B > 0 && N > 0 && M >= 0, "step_workspace_offsets: bad argument");
   StepWs w = carve_step(m, B, N, M, nullptr);
-  out7[0] = (size_t)((char*)w.hidden - (char*)nullptr);
-  out7[1] = (size_t)((char*)w.row_index - (char*)nullptr);
-  out7[2] = (size_t)((char*)w.src_rows - (char*)nullptr);
-  out7[3] = (size_t)((char*)w.count - (char*)nullptr);
-  out7[4] = (size_t)((char*)w.logits - (char*)nullptr);
-  out7[5] = (size_t)((char*)w.conf - (char*)nullptr);
-  out7[6] = (size_t)((char*)w.x0 - (char*)nullptr);
+  for (int i = 0; i < 7; ++i) out7[i] = w.off[i];
   return DARK_OK;
 }
 
@@ -272,7 +276,7 @@ struct HeadFuseWs {
 static HeadFuseWs carve_head_fuse(const dark_model_desc* m, size_t M, char* base) {
   HeadFuseWs w;
   size_t off = 0;
-  auto take = [&](size_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };  // (null base: sizes only)
   w.P = 4 * cdiv(m->vocab, 256);
   w.xn = take(M * m->d * esize(m->dtype));
   w.records = take(M * (size_t)w.P * 16);

@@ -145,7 +145,7 @@ static Gpt2Ws carve_gpt2(const dark_gpt2_desc* m, size_t rows, char* base) {
   const size_t es = esz(m->dtype);
   Gpt2Ws w;
   size_t off = 0;
-  auto take = [&](size_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };  // (null base: sizes only)
   w.xn = take(rows * m->d * es);
   w.qkv = take(rows * 3 * m->d * es);
   w.att = take(rows * m->d * es);
