@@ -76,6 +76,24 @@ def main():
         print(f"{name:18s}: first 200 launches {first:6.1f} us each, last {us:6.1f} us "
               f"({2.0 * M * N * K / us / 1e6:6.1f} TFLOP/s); smi samples (power, sclk): {smp.rows}", flush=True)
         time.sleep(1.0)
+        # the same launch at a low duty cycle: one launch, then ~4 launch-times of a one-thread busy-wait kernel (the
+        # chip idles at low power), timed by events around the GEMM alone -- what the kernel does when the power
+        # management has headroom
+        if epi == 2:
+            for gap_cycles in (0, 400_000, 1_600_000):
+                evs = []
+                for _ in range(300):
+                    if gap_cycles:
+                        torch.cuda._sleep(gap_cycles)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    lib.dark_dbg_gemm(1, epi, _hip.ptr(A), _hip.ptr(W), None, _hip.ptr(o), M, N, K, ldo, st)
+                    e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs[100:])
+                print(f"{name:18s}: idle gap of {gap_cycles:8d} busy-wait cycles between launches -> median {ts[len(ts) // 2]:6.1f} us, "
+                      f"min {ts[0]:6.1f} us per launch", flush=True)
 
 
 if __name__ == "__main__":
