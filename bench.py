@@ -78,7 +78,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=48, help="sequences in the CPU-oracle sample")
     ap.add_argument("--gemm-variant", type=int, default=0, choices=[0, 1, 2, 4, 5, 6, 7, 11],
                     help="A/B hook: 0 = the library's choice, 1 = 128-row GEMM kernels only, 2 / 4 = the persistent 256x256 "
-                         "kernel (plain / staggered) wherever it supports the shape")
+                         "kernel (plain / staggered) wherever it supports the shape; 6 / 7 / 11 = the library's choice "
+                         "without the down_proj routing / without the q/k/v routing / with o_proj on the persistent kernel")
     ap.add_argument("--residual-fp32", action="store_true",
                     help="A/B: carry the bf16 model's residual stream in fp32 (default: the model dtype, as the "
                          "reference's bf16 model does)")

@@ -7,8 +7,8 @@
 // identically.  Kernels of this file:
 //   bf16: gemm_bf16_kernel16<EPI, BNt> -- 128 x BNt block tile (BNt = 192, or 128 for the fp32-out flavours), 4 waves
 //         (2 x 2) of v_mfma_f32_16x16x32_bf16 tiles, BK = 64, two LDS stages filled by LDS-DMA, two workgroups per CU.
-//         Serves q/k/v + bias, o_proj + residual (and down_proj + residual where the persistent kernel does not take
-//         it: fp32 residual stream, few rows), the log-sum-exp head of the GRPO path, the GPT-2 epilogues, and every
+//         Serves o_proj + residual (and q/k/v + bias / down_proj + residual where the persistent kernel does not
+//         take them: fp32 residual stream, few rows), the log-sum-exp head of the GRPO path, the GPT-2 epilogues, and every
 //         launch too small for the persistent 256-wide kernels of gemm256.hip (pick_kernel below decides).  The
 //         residual flavours exist for an fp32 stream (EPI_RESID, EPI_RESID_BIAS) and for a bf16 one (.._H).
 //   fp32: gemm_f32_kernel<EPI> -- 128 x 128 tile, 4 waves of 2 x 2 v_mfma_f32_32x32x2_f32 tiles (an exact fp32 fma chain
@@ -705,15 +705,15 @@ void set_gemm_variant(int v) {
 // Automatic choice from the A/B of tools/gemm_ab.py (one process, interleaved rounds, M = 23552, random operands):
 //   gate/up + SwiGLU (N 6144):  128x192 196 us | p256 205 us | s256 188 us     -> s256
 //   LM head, fp32 out (N 15080): 128x128 706 us | p256 615 us | s256 611 us     -> s256
-//   q/k/v + bias (N 2304):       128x192  88 us | p256 101 us | s256  94 us     -> 128x192 (828 tiles over 256 CUs
-//                                                                                 leave the fourth round 23 % full)
+//   q/k/v + bias (N 2304):       128x192  88 us | p256 101 us | s256  94 us (256-row tiles: 828 tiles leave the fourth
+//                                round 23 % full; 288-row tiles, added later: 85 us -> s256, see below)
 // Few rows leave the 256 CUs short of 256 x 256 tiles: those launches stay on the 128-row kernels.
 static int pick_kernel(int dtype, int epi, int M, int N, int K, int64_t ldo, const void* out, const void* bias) {
   if (dtype != DARK_BF16) return 0;
   int v = g_gemm_variant.load(std::memory_order_relaxed);
-  // 6 / 7 = A/B of the automatic choice itself: 6 = without the one-round down_proj routing below, 7 = with q/k/v on
-  // the 288-row persistent kernel as well
-  const bool no_resid_s256 = v == 6, qkv_s256 = v == 7, oproj_s256 = v == 11;   // (11 = o_proj there too)
+  // 6 / 7 / 11 = A/B of the automatic choice itself: 6 = without the one-round down_proj routing below, 7 = without
+  // q/k/v on the 288-row persistent kernel, 11 = with o_proj there too
+  const bool no_resid_s256 = v == 6, qkv_s256 = v != 7, oproj_s256 = v == 11;
   if (v == 5 || v == 6 || v == 7 || v == 11) v = 0;  // 5 = automatic GEMM choice + the row-panel kernel for o_proj / down_proj (api.hip)
   if (v == 1) return 0;
   const bool p_ok = p256_supports(epi, M, N, K, ldo, out, bias), s_ok = s256_supports(epi, M, N, K, ldo, out, bias);
@@ -726,7 +726,9 @@ static int pick_kernel(int dtype, int epi, int M, int N, int K, int64_t ldo, con
   // 256 columns per CU (a round of the 128-row kernel = two 128 x 192 tiles per CU); the 128-row kernel's partial
   // rounds run faster than the model says (a lone workgroup has the CU to itself), hence the 10 % margin.  Measured
   // (tools/gemm_ab.py, M = 23552): 110 -> 88 us.  At K = 768 the one-round launch has no next tile to hide its
-  // prologue and epilogue behind and gains nothing (o_proj stays here).
+  // prologue and epilogue behind and gains nothing (o_proj stays here).  q/k/v + bias (N = 2304): 738 tiles of 288 x 256
+  // are three 96 %-full rounds against 4.3 rounds of 128 x 192: 85.2 vs 89.0 us, +0.2 % in the loop in three
+  // alternating pairs (profiles/r02ab_qkv_routing_ab.txt) -- small, but the same bits from one kernel family.
   if (s_ok && ((epi == EPI_RESID_H && (K >= 1536 || oproj_s256) && !no_resid_s256) || (epi == EPI_BIAS && qkv_s256))) {
     int cus = 256;
     const double c256 = s256_best_cost(epi, M, N, &cus);

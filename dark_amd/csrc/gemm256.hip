@@ -4,10 +4,10 @@
 //
 // Replaces the same nn.Linear calls as gemm.hip for the shapes where a 256-wide macro tile quantises well:
 // gate/up with the fused SwiGLU (modeling_dream_length.py:221-222), the LM head (:809), incl. the fused head's
-// slice-record flavour (EPI_HEAD), and down_proj + residual (:222, :514) on a bf16 residual stream, whose 23552 rows are
-// ONE 96 %-full round of 288 x 256 tiles.  gemm.hip keeps q/k/v (three rounds of 288-row tiles measure within 4 % of
-// its 4.3 rounds of 128 x 192), o_proj (K = 768: a one-round launch has nothing to hide its prologue and epilogue
-// behind), every residual GEMM on an fp32 stream and every launch with too few tiles (pick_kernel in gemm.hip).
+// slice-record flavour (EPI_HEAD), down_proj + residual (:222, :514) on a bf16 residual stream, whose 23552 rows are
+// ONE 96 %-full round of 288 x 256 tiles, and q/k/v + bias (:381-383: three 96 %-full rounds of 288-row tiles).
+// gemm.hip keeps o_proj (K = 768: a one-round launch has nothing to hide its prologue and epilogue behind), every
+// residual GEMM on an fp32 stream and every launch with too few tiles (pick_kernel in gemm.hip).
 //
 // Why another kernel: the 128 x 192 kernel of gemm.hip moves (128 + 192) * 128 B from L2 into LDS per 128*192*64
 // MACs and reads 10 fragments per 24 MFMAs; a 256 x 256 tile with 128 x 64 per wave moves 39 % fewer bytes per MAC

@@ -449,8 +449,8 @@ int dark_dbg_gemm_resid_norm(const void* A, const void* W, float* hidden, const 
  *   4 = its staggered two-group form (gemm_bf16_s256) wherever it supports the shape, automatic tile height;
  *   8 / 9 / 10 = the same with the tile height forced to 256 / 288 / 320 rows;
  *   5 = the library's choice + the row-panel kernel for the residual projections (fp32 residual stream only);
- *   6 / 7 / 11 = the library's choice without its one-round down_proj routing / with q/k/v / with o_proj on the
- *   persistent kernel as well (the in-loop A/Bs recorded in DESIGN.md);
+ *   6 / 7 / 11 = the library's choice without its one-round down_proj routing / without q/k/v on the persistent
+ *   kernel / with o_proj there too (the in-loop A/Bs recorded in DESIGN.md);
  *   16 + p = timing probe p of gemm_bf16_s256 (WRONG results unless p = 8 or 9: per-phase cycle sums). */
 int dark_dbg_set_gemm_variant(int variant);
 int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
