@@ -27,10 +27,11 @@
 
 namespace dark {
 
-constexpr int ST = 512;         // threads per row (8 waves)
+constexpr int ST = 768;         // threads per row: 12 waves (2 workgroups per CU by LDS = 24 waves, 78 VGPRs allow 24; with 8
+                                // waves the VALU-bound mass pass had 4 waves per SIMD to hide its LDS reads: +0.3 % in the loop)
 constexpr int NLIN = 1024;      // linear bins of stage 1
 constexpr int NRAD = 256;       // radix bins of the fallback select
-constexpr int CAND_CAP = ST;         // candidates resolved exactly, one per thread
+constexpr int CAND_CAP = 512;        // candidates resolved exactly, one per thread (CAND_CAP <= ST)
 constexpr float HEAD_RANGE = 6.0f;    // head path: candidates are the logits within this of the row maximum
 constexpr float LIN_RANGE = 28.0f;
 #define DARK_FLT_LOWEST (-3.4028234663852886e38f)  // torch.finfo(torch.float32).min
@@ -76,11 +77,11 @@ __device__ __forceinline__ int lin_bin(float l, float mx) {
 }
 
 struct Scratch {
-  unsigned long long u64[8], u64b[8];
-  double f64a[8], f64b[8];
-  float f32a[8], f32b[8], f32c[8];
-  int i32[8];
-  uint32_t u32[8];
+  unsigned long long u64[ST / 64], u64b[ST / 64];   // one slot per wave
+  double f64a[ST / 64], f64b[ST / 64];
+  float f32a[ST / 64], f32b[ST / 64], f32c[ST / 64];
+  int i32[ST / 64];
+  uint32_t u32[ST / 64];
   // select broadcast
   int found, bin, ncand;
   unsigned long long above;
