@@ -208,7 +208,7 @@ def main():
                      "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4),
                      # HBM-side bytes per launch from rocprofv3 PMC (FETCH_SIZE doubled per the gfx950 note, +
-                     # WRITE_SIZE), separate passes, profiles/r02zt_pmc.txt; valid for the default shape and kernel
+                     # WRITE_SIZE), separate passes, profiles/r02zzf_pmc.txt; valid for the default shape and kernel
                      "traffic": 453.6e6 if (args.dtype == "bf16" and args.batch == 1024 and args.gemm_variant == 0) else None,
                      "algorithmic_bytes": 2.0 * (half * 46 * 768 + 6144 * 768 + half * 46 * 3072),
                      "launches": n.value,
