@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on ONE card: every rank uses cuda:0 and the collectives run over gloo (a functional "
                          "rehearsal of the multi-GPU path, not a measurement)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the collectives at world size 1 too (takes the nccl = "
+                         "RCCL branch on a 1-GPU box; needs RANK / WORLD_SIZE / MASTER_* as a launcher sets them)")
     ap.add_argument("--workload", default="denoise", choices=["denoise", "expand", "logprob"],
                     help="denoise = the headline (BASELINE config 2); expand / logprob = the widened paths of SURVEY "
                          "8f-1 / 8f-3 on one GPU (tools/bench_expand.py, tools/bench_logprob.py) with their CPU-oracle legs")
@@ -102,7 +105,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    grouped = world > 1 or args.force_dist
+    if grouped:
         if args.rehearse:
             dist.init_process_group("gloo")
         else:
@@ -110,6 +114,7 @@ def main():
 
     from dark_amd import DreamConfig, DreamGenerationConfig, DreamModel_length, _hip, dispatch, synth
 
+    dispatch.FORCE_COLLECTIVES = bool(args.force_dist)
     lib = _hip.load()
     _hip.check(lib.dark_dbg_set_gemm_variant(args.gemm_variant))
     cfg = DreamConfig(vocab_size=synth.vocab_size(**synth.FB15K237), mask_token_id=synth.MASK,
@@ -139,13 +144,13 @@ def main():
         for ids in (ids_abd, ids_ded):
             seqs.append(model.diffusion_generate(ids, generation_config=gc, **dict(gen_kw, **over)))
         out = torch.cat(seqs, 0)
-        if world > 1:  # per-batch result gather (replaces all_gather_object of mdm_unify.py:436-438)
+        if grouped:  # per-batch result gather (replaces all_gather_object of mdm_unify.py:436-438)
             out = dispatch.gather_rows(out, out.shape[0] * world)
         return out
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -174,7 +179,7 @@ def main():
     fence()
     dt_skip = time.perf_counter() - t1
 
-    if world > 1:
+    if grouped:
         t = torch.tensor([dt, dt_skip], device="cpu" if args.rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_skip = float(t[0]), float(t[1])
@@ -195,7 +200,8 @@ def main():
                                "(10L d768 ff3072 H8, V=15080, N=46)",
                    "batch_per_gpu": args.batch, "denoise_steps": args.denoise_steps, "temperature": 0.1,
                    "top_p": 0.9, "alg": "entropy", "parallelism": f"dp{world}", "weights": "random-init",
-                   "residual_stream": "f32" if (args.residual_fp32 or args.dtype == "f32") else "bf16"},
+                   "residual_stream": "f32" if (args.residual_fp32 or args.dtype == "f32") else "bf16",
+                   **({"collectives": "nccl (forced at world size 1)"} if args.force_dist and not args.rehearse else {})},
         "value_skip_noop_steps": round(args.batch * world * args.steps / dt_skip, 2),
         # SURVEY 8(d)'s algorithmic FLOPs (every row through every layer, head on masked rows) over the dense peak ...
         "forward_mfma_frac": round(alg_flops * args.steps * world / dt / 1e12 / (peak * world), 4),
@@ -219,7 +225,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(cfg, weights, args, synth)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -22,6 +22,15 @@ import torch
 import torch.distributed as dist
 
 
+# Tests and `bench.py --force-dist` set this to run every collective at world size 1 as well: a single rank on one
+# card is the only way to take the RCCL (`nccl`) branches on a 1-GPU box (RCCL refuses two ranks on one device).
+FORCE_COLLECTIVES = False
+
+
+def _single(world: int) -> bool:
+    return world == 1 and not (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
 def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous row block of `rank`: sizes differ by at most one, larger blocks first."""
     if world <= 0 or not 0 <= rank < world:
@@ -49,7 +58,7 @@ def gather_rows(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     """all_gather of row blocks produced by `shard_bounds` -> the `[total, ...]` tensor on every rank.
     Blocks are padded to the largest block so that one fixed-size collective moves everything."""
     world, rank = _world(group)
-    if world == 1:
+    if _single(world):
         return local
     lo, hi = shard_bounds(total, world, rank)
     if local.shape[0] != hi - lo:
@@ -88,7 +97,7 @@ def global_mask_count(local_count: torch.Tensor, local_batch: int, group=None) -
     mask count of generation_utils.py:520.  `local_count` is a one-element integer tensor on the device the
     backend communicates from."""
     world, _ = _world(group)
-    if world == 1:
+    if _single(world):
         return int(local_count), local_batch
     t = torch.stack([local_count.reshape(()).to(torch.int64),
                      torch.tensor(local_batch, dtype=torch.int64, device=local_count.device)])
@@ -118,11 +127,11 @@ def generate_sharded(model, inputs: torch.Tensor, generation_config=None, *, gro
     kwargs["return_dict_in_generate"] = False
     if attention_mask is not None:
         kwargs["attention_mask"] = attention_mask[lo:hi]
-    if exact_ragged_k and world > 1:
+    if exact_ragged_k and not _single(world):
         if total < world:
             raise ValueError("exact_ragged_k needs at least one row per rank (every rank joins the per-step all-reduce)")
         kwargs["_count_reduce"] = lambda cnt, b: global_mask_count(cnt, b, group)
-    if shard_head and world > 1:
+    if shard_head and not _single(world):
         if total < world:
             raise ValueError("shard_head needs at least one row per rank (every rank joins the per-step exchanges)")
         from .vocab_shard import ShardedHead

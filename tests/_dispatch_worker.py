@@ -61,8 +61,48 @@ def shard_mode(rank, world, prefix):
     torch.save(res, f"{prefix}.rank{rank}.pt")
 
 
+def nccl_single_rank(prefix):
+    """ONE rank on cuda:0 over `nccl` (= RCCL) with dispatch.FORCE_COLLECTIVES: every collective of the multi-GPU
+    path (all_gather of sequences / records / hidden rows / flags, all_reduce SUM of the mask count and MAX of the row
+    maxima, all_to_all of the shard records, barrier) runs through RCCL on device tensors of the dtypes the real run
+    uses -- the only way to take those branches on a 1-GPU box -- and must leave the results unchanged."""
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl"
+    m = build()
+    rag = ragged_inputs().to("cuda:0")
+    kw = dict(steps=8, temperature=0.0, alg="entropy", alg_temp=0, top_p=0.9)
+    res = {"plain_ragged": m.diffusion_generate(rag, generation_config=gen_config(), **kw).cpu()}
+    ids = synth.make_inputs(12, "ded", seed=23).to("cuda:0")
+    kw5 = dict(steps=10, temperature=0.5, alg="entropy", alg_temp=0, top_p=0.9)
+    torch.manual_seed(300)
+    res["plain_t05"] = m.diffusion_generate(ids, generation_config=gen_config(), **kw5).cpu()
+    dispatch.FORCE_COLLECTIVES = True
+    res["nccl_ragged"] = dispatch.generate_sharded(m, rag, gen_config(), exact_ragged_k=True, **kw).cpu()
+    torch.manual_seed(300)
+    res["nccl_shard_head"] = dispatch.generate_sharded(m, ids, gen_config(), shard_head=True, **kw5).cpu()
+    bf = build().to(torch.bfloat16)          # bf16 hidden rows through the all_gather
+    torch.manual_seed(301)
+    res["plain_bf16"] = bf.diffusion_generate(ids, generation_config=gen_config(), **kw5).cpu()
+    torch.manual_seed(301)
+    res["nccl_bf16_shard_head"] = dispatch.generate_sharded(bf, ids, gen_config(), shard_head=True, **kw5).cpu()
+    scores = torch.arange(6, dtype=torch.float32).view(3, 2)
+    pid = torch.tensor([1, 2, 3], dtype=torch.int32)
+    sc, pi = dispatch.gather_metric_records(scores.to("cuda:0"), pid.to("cuda:0"), 3)
+    res["scores"], res["pattern_id"] = sc.cpu(), pi.cpu()
+    t = torch.tensor([1.5, 2.5], device="cuda:0", dtype=torch.float64)   # bench.py's max-over-ranks of the timings
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    res["f64_max"] = t.cpu()
+    dist.barrier()
+    torch.cuda.synchronize()
+    torch.save(res, f"{prefix}.rank0.pt")
+    dist.destroy_process_group()
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if len(sys.argv) > 2 and sys.argv[2] == "nccl1":
+        return nccl_single_rank(sys.argv[1])
     dist.init_process_group("gloo")
     torch.cuda.set_device(0)
     if len(sys.argv) > 2 and sys.argv[2] == "shard":

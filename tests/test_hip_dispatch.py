@@ -67,6 +67,31 @@ def test_generate_sharded_real_model_world2(tmp_path):
     assert res[0]["pattern_id"].tolist() == [1, 2, 3, 11, 12, 13]
 
 
+def test_rccl_single_rank_collectives(tmp_path):
+    """The `nccl` (= RCCL) branches of dispatch / vocab_shard, which two ranks sharing one card cannot take (RCCL refuses
+    a device twice): one rank, every collective forced to run, results equal to the plain calls."""
+    res = _run_ranks(1, str(tmp_path / "nccl"), "nccl1")[0]
+    assert torch.equal(res["nccl_ragged"], res["plain_ragged"])
+    assert torch.equal(res["nccl_shard_head"], res["plain_t05"])
+    assert torch.equal(res["nccl_bf16_shard_head"], res["plain_bf16"])
+    assert res["scores"].tolist() == [[0, 1], [2, 3], [4, 5]] and res["pattern_id"].tolist() == [1, 2, 3]
+    assert res["f64_max"].tolist() == [1.5, 2.5]
+
+
+def test_bench_nccl_branch_single_rank():
+    """bench.py's `nccl` branch (process-group init on the device, barrier, gather of the sequences, max over ranks of
+    the timings) at world size 1 under the launcher's environment."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "1",
+                        "--warmup", "0", "--batch", "64", "--denoise-steps", "8", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["collectives"] == "nccl (forced at world size 1)"
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher must start two ranks itself and print ONE JSON line (rc 0);
     --rehearse puts both on cuda:0 over gloo (a functional rehearsal: the value is not a measurement)."""
