@@ -18,8 +18,9 @@ LIB_PATH = os.path.join(_HERE, "libdark_hip.so")
 DARK_OK, DARK_ERR_ARG, DARK_ERR_HIP, DARK_ERR_UNSUPPORTED = 0, 1, 2, 3
 DARK_F32, DARK_BF16 = 0, 1
 CONF_PROB, CONF_MARGIN, CONF_NEG_ENTROPY = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 SHARD_PART_BYTES = 280
+SAMPLE_LDS_MAX_V = 32768   # DARK_SAMPLE_LDS_MAX_V: larger vocabularies sample from a registered row workspace
 
 
 class LayerWeights(C.Structure):
@@ -77,6 +78,7 @@ SIGNATURES = {
     "dark_sample_rows_philox": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                           C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    "dark_sampler_set_row_workspace": (C.c_int, [C.c_void_p, C.c_size_t]),
     "dark_philox_exponential": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     "dark_final_norm_rows": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "dark_lm_head_shard": (C.c_int, [C.POINTER(ModelDesc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -180,7 +182,43 @@ def load() -> C.CDLL:
     if got != ABI_VERSION:
         raise ImportError(f"libdark_hip.so ABI version {got}, binding expects {ABI_VERSION}")
     _lib = lib
+    # every entry point that samples registers the large-vocabulary row workspace first (a no-op for V <= 32768)
+    for name, (m_at, v_at) in _SAMPLING_CALLS.items():
+        setattr(lib, name, _with_row_workspace(getattr(lib, name), m_at, v_at))
     return lib
+
+
+# (index of M, index of V or None = args[0] is a model descriptor) in the argument lists of the sampling entry points
+_SAMPLING_CALLS = {"dark_sample_rows": (2, 3), "dark_sample_rows_philox": (2, 3), "dark_sample_rows_indexed": (2, 3),
+                   "dark_head_sample_rows": (3, None), "dark_denoise_step": (6, None)}
+_row_ws = {}   # device index -> uint8 tensor registered with dark_sampler_set_row_workspace
+
+
+def ensure_sampler_rows(M: int, V: int) -> None:
+    """Vocabularies beyond DARK_SAMPLE_LDS_MAX_V (WN18RR: 41 066): the sampler keeps its rows in a device workspace
+    that the caller registers, because no entry point allocates.  One buffer per device (the CURRENT device, which
+    the library requires to be the tensors' device), grown when a call needs more, shared by every model on it."""
+    if V <= SAMPLE_LDS_MAX_V or M <= 0:
+        return
+    need = M * ((V + 3) & ~3) * 4
+    dev = torch.cuda.current_device()
+    buf = _row_ws.get(dev)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", dev))
+        check(_lib.dark_sampler_set_row_workspace(buf.data_ptr(), buf.numel()))
+        _row_ws[dev] = buf   # (the previous buffer returns to torch's allocator: reuse is ordered on the stream)
+
+
+def _with_row_workspace(fn, m_at: int, v_at):
+    import functools
+
+    @functools.wraps(fn)
+    def call(*args):
+        V = args[v_at] if v_at is not None else getattr(getattr(args[0], "_obj", None), "vocab", 0)
+        if V > SAMPLE_LDS_MAX_V:
+            ensure_sampler_rows(int(args[m_at]), int(V))
+        return fn(*args)
+    return call
 
 
 def check(rc: int) -> None:

@@ -295,7 +295,7 @@ static bool head_fuse_applies(const dark_model_desc* m, int M, float temperature
   if (gemm_variant() == 1) return false;  // A/B hook: variant 1 = the unfused head
   if (m->dtype != DARK_BF16 || !(temperature > 0.f) || !(top_p >= 0.f && top_p < 1.f)) return false;
   if (top_k > 0 && top_k < m->vocab) return false;
-  if (M < 1024 || m->vocab > 32768 || m->vocab % 4 != 0 || m->d % 64 != 0) return false;  // (16-byte logit stores)
+  if (M < 1024 || m->vocab > DARK_SAMPLE_LDS_MAX_V || m->vocab % 4 != 0 || m->d % 64 != 0) return false;  // (16-byte logit stores)
   // (the fallback GEMM addresses the logits with 32-bit byte offsets: very large M x V takes the two-call form)
   return head_gemm_supports(M, m->vocab, m->d) && s256_supports(EPI_F32, M, m->vocab, m->d, ldl, logits, nullptr);
 }
@@ -446,6 +446,8 @@ int dark_sample_rows_philox(const float* logits, int64_t ldl, int M, int V, floa
   return launch_sample_philox(logits, ldl, M, V, temperature, top_p, top_k, conf_mode, nullptr, 0, seed, offset,
                               nthreads, conf, x0, (hipStream_t)stream);
 }
+
+int dark_sampler_set_row_workspace(void* ptr, size_t bytes) { return set_sampler_row_workspace(ptr, bytes); }
 
 int dark_philox_exponential(uint64_t seed, uint64_t offset, uint32_t nthreads, uint64_t numel, float* out,
                             void* stream) {

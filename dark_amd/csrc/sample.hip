@@ -482,17 +482,23 @@ __device__ void list_tail_wave(const uint32_t* cand, const unsigned long long* c
   if (conf_mode == DARK_CONF_PROB && my_e > 0.f && my_idx == bi) *conf_out = my_p;  // after lane 0's store
 }
 
-__global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ logits, int64_t ldl, int V,
-                                                    float temperature, float top_p, int top_k, int conf_mode,
-                                                    const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
-                                                    float* __restrict__ conf, int64_t* __restrict__ x0,
-                                                    const int32_t* __restrict__ row_ids,
-                                                    const int32_t* __restrict__ n_dev) {
+// GROW = false: the row lives in LDS (V <= SAMPLE_LDS_MAX_V, every vocabulary the benchmarked configs use).
+// GROW = true: a vocabulary whose fp32 row does not fit in a CU's 160 KiB of LDS (WN18RR: V = 41 066 = 164 KB) keeps
+// the row in the caller-registered device workspace (dark_sampler_set_row_workspace), one [vp] slice per workgroup;
+// the program is the same, pass for pass, so the results are the same function of the row.  Global memory written by
+// one wave is read by the others behind __syncthreads(): all waves of a workgroup share their CU's L1.
+template <bool GROW>
+__device__ __forceinline__ void sample_row(const float* __restrict__ logits, int64_t ldl, int V,
+                                           float temperature, float top_p, int top_k, int conf_mode,
+                                           const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
+                                           float* __restrict__ conf, int64_t* __restrict__ x0,
+                                           const int32_t* __restrict__ row_ids,
+                                           const int32_t* __restrict__ n_dev, float* __restrict__ row_ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (n_dev && (int)blockIdx.x >= *n_dev) return;  // row count from device memory (block-uniform)
   const int vp = (V + 3) & ~3;
-  float* row = (float*)smem;
-  unsigned long long* hist = (unsigned long long*)(smem + (size_t)vp * 4);  // NLIN u64; radix hist/cnt alias it
+  float* row = GROW ? row_ws + (size_t)blockIdx.x * vp : (float*)smem;
+  unsigned long long* hist = (unsigned long long*)(smem + (GROW ? 0 : (size_t)vp * 4));  // NLIN u64; radix hist/cnt alias it
   unsigned int* cnth = (unsigned int*)(hist + NRAD);
   unsigned long long* cfx = hist + NLIN;
   uint32_t* cand = (uint32_t*)(cfx + CAND_CAP);
@@ -756,6 +762,42 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
   }
 }
 
+__global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ logits, int64_t ldl, int V,
+                                                    float temperature, float top_p, int top_k, int conf_mode,
+                                                    const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
+                                                    float* __restrict__ conf, int64_t* __restrict__ x0,
+                                                    const int32_t* __restrict__ row_ids,
+                                                    const int32_t* __restrict__ n_dev) {
+  sample_row<false>(logits, ldl, V, temperature, top_p, top_k, conf_mode, noise, ldn, pn, conf, x0, row_ids, n_dev, nullptr);
+}
+
+__global__ __launch_bounds__(ST) void sample_bigv_kernel(const float* __restrict__ logits, int64_t ldl, int V,
+                                                         float temperature, float top_p, int top_k, int conf_mode,
+                                                         const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
+                                                         float* __restrict__ conf, int64_t* __restrict__ x0,
+                                                         const int32_t* __restrict__ row_ids,
+                                                         const int32_t* __restrict__ n_dev, float* __restrict__ row_ws) {
+  sample_row<true>(logits, ldl, V, temperature, top_p, top_k, conf_mode, noise, ldn, pn, conf, x0, row_ids, n_dev, row_ws);
+}
+
+// Row workspace of the large-vocabulary sampler, one registration per device (see dark_hip.h).
+namespace {
+struct RowWorkspace { std::atomic<void*> ptr{nullptr}; std::atomic<size_t> bytes{0}; };
+RowWorkspace g_row_ws[DARK_MAX_DEVICES];
+}  // namespace
+
+int set_sampler_row_workspace(void* ptr, size_t bytes) {
+  int dev = 0;
+  DARK_CHECK_HIP(hipGetDevice(&dev));
+  DARK_CHECK_ARG(dev >= 0 && dev < DARK_MAX_DEVICES, "device ordinal %d out of range", dev);
+  DARK_CHECK_ARG((ptr == nullptr) == (bytes == 0) && ((uintptr_t)ptr & 15) == 0,
+                 "sampler_set_row_workspace: needs a 16-byte aligned device pointer with its size, or (NULL, 0)");
+  g_row_ws[dev].bytes.store(0, std::memory_order_release);
+  g_row_ws[dev].ptr.store(ptr, std::memory_order_release);
+  g_row_ws[dev].bytes.store(bytes, std::memory_order_release);
+  return DARK_OK;
+}
+
 int launch_philox_exponential(uint64_t seed, uint64_t offset, uint32_t nthreads, uint64_t numel, float* out,
                               hipStream_t st) {
   DARK_CHECK_ARG(out && nthreads > 0 && numel > 0 && numel < (1ull << 40), "philox_exponential: bad argument");
@@ -784,7 +826,7 @@ int launch_sample_indexed(const float* logits, int64_t ldl, int M, int V, float 
                           uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, hipStream_t st,
                           const int32_t* n_dev) {
   if (M <= 0) return DARK_OK;
-  DARK_CHECK_ARG(V >= 2 && V <= 32768, "sample_rows: V=%d must be in [2, 32768]", V);
+  DARK_CHECK_ARG(V >= 2 && V <= DARK_SAMPLE_MAX_V, "sample_rows: V=%d must be in [2, %d]", V, DARK_SAMPLE_MAX_V);
   DARK_CHECK_ARG(ldl >= V, "sample_rows: ldl < V");
   DARK_CHECK_ARG(logits && conf && x0, "sample_rows: null pointer");
   DARK_CHECK_ARG(conf_mode >= 0 && conf_mode <= 2, "sample_rows: bad conf_mode %d", conf_mode);
@@ -794,6 +836,24 @@ int launch_sample_indexed(const float* logits, int64_t ldl, int M, int V, float 
   DARK_CHECK_ARG(temperature >= 0.f, "sample_rows: negative temperature");
   DARK_CHECK_ARG(nthreads <= (1u << 30), "sample_rows: Philox grid of %u threads", nthreads);
   static_assert(NRAD * 12 <= NLIN * 8, "the radix histograms alias the linear histogram");
+  if (V > DARK_SAMPLE_LDS_MAX_V) {  // the row does not fit in LDS: rows live in the registered workspace
+    constexpr int smem_big = NLIN * 8 + CAND_CAP * 16 + (int)sizeof(Scratch);
+    static SmemOptIn optin_big;   // (no opt-in needed at this size; the call checks that the stream's device is current)
+    DARK_TRY(optin_big.ensure((const void*)sample_bigv_kernel, smem_big, st));
+    int dev = 0;
+    DARK_CHECK_HIP(hipGetDevice(&dev));
+    const size_t need = (size_t)M * (size_t)((V + 3) & ~3) * 4;
+    const size_t have = g_row_ws[dev].bytes.load(std::memory_order_acquire);
+    float* ws = (float*)g_row_ws[dev].ptr.load(std::memory_order_acquire);
+    DARK_CHECK_ARG(ws && have >= need,
+                   "sample_rows: V=%d exceeds the LDS-resident sampler (V <= %d): register a row workspace of at least "
+                   "%zu bytes on device %d with dark_sampler_set_row_workspace (registered: %zu)",
+                   V, DARK_SAMPLE_LDS_MAX_V, need, dev, have);
+    hipLaunchKernelGGL(sample_bigv_kernel, dim3(M), dim3(ST), smem_big, st, logits, ldl, V, temperature, top_p, top_k,
+                       conf_mode, noise, ldn, pn, conf, x0, row_ids, n_dev, ws);
+    DARK_CHECK_LAUNCH();
+    return DARK_OK;
+  }
   const int smem = ((V + 3) & ~3) * 4 + NLIN * 8 + CAND_CAP * 16 + (int)sizeof(Scratch);
   static SmemOptIn optin;
   DARK_TRY(optin.ensure((const void*)sample_kernel, smem, st));

@@ -22,6 +22,7 @@ OFFSET = 100
 QRY_LEN, ANS_LEN = 10, 32
 FB15K237 = dict(nentity=14505, nrelation=474)   # V = 100 + 14505 + 474 + 1 = 15080
 DBPEDIA50 = dict(nentity=24624, nrelation=702)  # V = 25427
+WN18RR = dict(nentity=40943, nrelation=22)      # V = 41066 (11 relations, doubled for inverse edges, load_kg_util.py:116-118)
 
 
 def vocab_size(nentity: int, nrelation: int) -> int:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DARK_HIP_ABI_VERSION 5
+#define DARK_HIP_ABI_VERSION 6
 
 #define DARK_OK 0
 #define DARK_ERR_ARG 1         /* bad shape / pointer / unsupported size */
@@ -156,6 +156,18 @@ int dark_mask_rows(const int64_t* x, int B, int N, int64_t mask_id, int32_t* row
 int dark_sample_rows(const float* logits, int64_t ldl, int M, int V, float temperature, float top_p,
                      int top_k, int conf_mode, const float* noise, int64_t ldn, float* conf,
                      int64_t* x0, void* stream);
+
+/* Vocabularies beyond DARK_SAMPLE_LDS_MAX_V (the reference's WN18RR vocabulary is 100 + 40 943 entities + 22
+ * relations + 1 = 41 066, akgr/tokenizer.py:19-27; its fp32 row no longer fits in a CU's LDS): every sampler entry
+ * point (dark_sample_rows / _philox / _indexed, and the calls that sample inside dark_head_sample_rows and
+ * dark_denoise_step) then keeps the rows it works on in a device workspace of M * ((V + 3) & ~3) * 4 bytes that the
+ * caller registers ONCE per device (the current device of the call), since no entry point allocates.  Same program,
+ * same results as a function of the row; logits stay read-only.  The registration holds until it is replaced ((NULL, 0)
+ * clears it); sampler calls that overlap on one GPU share it and race, as with any workspace.  A sampler call with
+ * V > DARK_SAMPLE_LDS_MAX_V and no sufficient registration returns DARK_ERR_ARG with the size it needs. */
+#define DARK_SAMPLE_LDS_MAX_V 32768
+#define DARK_SAMPLE_MAX_V (1 << 22)
+int dark_sampler_set_row_workspace(void* ptr, size_t bytes);
 
 /* dark_sample_rows with the Exp(1) draws computed where they are consumed instead of read from a [M, V] buffer:
  * element (m, v) is element m*V + v of what `torch.empty(M, V).exponential_()` writes on this device for a generator

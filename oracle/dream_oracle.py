@@ -33,6 +33,8 @@ import math
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple
 
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -148,12 +150,35 @@ def forward_logits(w, cfg, input_ids, attn_mask=None, position_ids=None) -> torc
 
 
 # --------------------------------------------------------------------------- sampling
+# exact_nucleus(): evaluate the nucleus prefix sums of top_p_logits in float64 instead of the reference's fp32.  The
+# reference's kept set is `cumsum(softmax(sorted)) > top_p` in fp32; the normaliser of an fp32 softmax over V terms
+# carries a relative error of a few 1e-6 at V = 41 066 (measured on this torch build: a row whose first 39 tokens hold
+# 0.8999976 of the mass comes out as 0.9000022 and loses its 40th token), so which side of top_p a prefix sum within
+# that distance falls on is decided by rounding, differently on a CPU and on a device.  Tests of large vocabularies
+# compare the kernel (integer masses, good to 2.4e-7) with this exactly-evaluated form of the same rule.
+_NUCLEUS_FP64 = False
+
+
+@contextlib.contextmanager
+def exact_nucleus():
+    global _NUCLEUS_FP64
+    prev, _NUCLEUS_FP64 = _NUCLEUS_FP64, True
+    try:
+        yield
+    finally:
+        _NUCLEUS_FP64 = prev
+
+
 def top_p_logits(logits: torch.Tensor, top_p: float, stable_ties: bool = False) -> torch.Tensor:
     """generation_utils.py:37-48.  The reference's `torch.sort` leaves the order inside a run of equal logits
     unspecified, so which members of a run that straddles the nucleus boundary survive is not pinned by it;
     `stable_ties=True` fixes index order (the device's rule) for tests that plant such runs."""
     sorted_logits, sorted_idx = torch.sort(logits, descending=True, stable=stable_ties)
-    cum = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1)
+    if _NUCLEUS_FP64:
+        cum = torch.cumsum(F.softmax(sorted_logits.double(), dim=-1), dim=-1)
+        top_p = float(torch.tensor(top_p, dtype=logits.dtype))   # the threshold the fp32 comparison uses
+    else:
+        cum = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1)
     remove = cum > top_p
     remove[..., 1:] = remove[..., :-1].clone()
     remove[..., 0] = 0

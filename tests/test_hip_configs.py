@@ -163,6 +163,72 @@ def test_config3_full_size_properties_bf16(real):
         prev = cur
 
 
+# --------------------------------------------------------------------------- WN18RR (V = 41066 > the LDS-resident sampler)
+def test_wn18rr_vocab_loop_vs_oracle(real):
+    """The reference's third dataset (configs/config-sampling.yml:3): V = 100 + 40 943 + 22 + 1 = 41 066, whose fp32
+    logits row (164 KB) does not fit in LDS -- the sampler runs from the registered row workspace.  Whole loop in fp32
+    on a 2-layer cut of the real width against the oracle on injected noise, T = 0.1 (head path) and 0.5 (flat rows)."""
+    meta, _ = real
+    kw = dict(meta["cfg3"], vocab_size=synth.vocab_size(**synth.WN18RR))
+    assert kw["vocab_size"] == 41066 > _hip.SAMPLE_LDS_MAX_V
+    m = _model(kw)
+    w = synth.make_weights(m.config, seed=0, rich=False)
+    for kind, T, B in (("abd", 0.1, 12), ("abd", 0.5, 12)):   # (as test_config3_vocab_loop_vs_oracle: abduction rows)
+        ids = synth.make_inputs(B, kind, seed=47 + int(10 * T), **synth.WN18RR)
+        g = torch.Generator().manual_seed(19)
+        noises = {}
+
+        def noise_fn(step, M, V):
+            if step not in noises:
+                noises[step] = torch.empty(M, V).exponential_(1, generator=g)
+            return noises[step]
+
+        trace = {}
+        out = m.diffusion_generate(inputs=ids.to(DEV), generation_config=_gc(), return_dict_in_generate=True,
+                                   output_history=True, steps=12, temperature=T, alg="entropy", alg_temp=0, top_p=0.9,
+                                   _noise_fn=noise_fn, _trace=trace)
+        otr = O.SampleTrace()
+        with O.exact_nucleus():   # at this V the fp32 prefix sums of the reference are rounding-decided (oracle header)
+            _, hist = O.sample_loop(w, _ocfg(kw), ids, max_length=46, steps=12, mask_token_id=synth.MASK,
+                                    alg="entropy", alg_temp=0, temperature=T, top_p=0.9,
+                                    noise_fn=lambda s, M, V: noises[s], trace=otr, tie_break="index")
+        assert trace["k"] == otr.k
+        for i in range(12):
+            assert torch.equal(trace["x0"][i].cpu(), otr.x0[i]), f"{kind}: x0 differs at step {i}"
+            np.testing.assert_allclose(trace["confidence"][i].cpu().numpy(), otr.confidence[i].numpy(), rtol=1e-3, atol=1e-5)
+            assert torch.equal(out.history[i].cpu(), hist[i]), f"{kind}: history differs at step {i}"
+
+
+def test_wn18rr_full_depth_bf16_lazy_noise_properties(real):
+    """WN18RR's vocabulary at the full 10-layer shape in bf16 with the lazy Philox noise (the product's default path:
+    head GEMM at N = 41 066, row-workspace sampler, dark_sample_rows_philox): same seed -> same trajectory, the lazy
+    noise equals the materialised fill, and the loop's invariants hold."""
+    meta, _ = real
+    kw = dict(meta["real"], vocab_size=41066)
+    m = _model(kw, torch.bfloat16)
+    ids = synth.make_inputs(96, "ded", seed=22, **synth.WN18RR).to(DEV)
+    runs = []
+    for lazy in (True, True, False):
+        torch.manual_seed(79)
+        out = m.diffusion_generate(inputs=ids, generation_config=_gc(), return_dict_in_generate=True,
+                                   output_history=True, steps=32, temperature=0.1, alg="entropy", alg_temp=0,
+                                   top_p=0.9, skip_noop_steps=False, lazy_noise=lazy)
+        runs.append(torch.stack(out.history))
+    assert torch.equal(runs[0], runs[1]), "same seed, same inputs: trajectories must be identical"
+    assert torch.equal(runs[0], runs[2]), "lazy Philox noise must equal torch's materialised exponential_ fill"
+    prev = torch.nn.functional.pad(ids, (0, 1), value=synth.MASK)
+    left = 33
+    for step, k in enumerate(O.transfer_schedule(33, 32)):
+        cur = runs[0][step]
+        was_mask = prev == synth.MASK
+        assert torch.equal(cur[~was_mask], prev[~was_mask]), f"step {step}: an unmasked position changed"
+        left -= k
+        cnt = (cur == synth.MASK).sum(1)
+        assert bool(((cnt == left) | (cnt == left + 1)).all()), f"step {step}"
+        assert bool(((cur >= 0) & (cur < 41066)).all())
+        prev = cur
+
+
 # --------------------------------------------------------------------------- real-width reference goldens
 def test_real_shape_deduction_and_config1_goldens(real):
     """Full 10-layer default shape, fp32: a deduction batch (33 masks) at T = 0.1 and T = 0.5 over 32 steps and

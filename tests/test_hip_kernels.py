@@ -360,6 +360,91 @@ def test_sample_rows_dbpedia_vocab(lib):
     np.testing.assert_allclose(conf.numpy(), rc.numpy(), rtol=3e-5, atol=1e-6)
 
 
+WN18RR_V = 100 + 40943 + 22 + 1   # akgr/tokenizer.py:19-27 with WN18RR's counts: 41 066 > DARK_SAMPLE_LDS_MAX_V
+
+
+@pytest.mark.parametrize("T,top_p,top_k,margin,negent", [
+    (0.0, None, None, False, False), (0.1, 0.9, None, False, True), (0.5, 0.9, None, False, True),
+    (1.0, 0.95, None, True, False), (0.7, None, 50, False, True), (0.3, 0.8, 7, False, False)])
+def test_sample_rows_wn18rr_vocab(lib, T, top_p, top_k, margin, negent):
+    """The reference's third dataset: a 164 KB fp32 row does not fit in LDS, the sampler works on the registered row
+    workspace (sample_bigv_kernel).  Against the oracle, as for the other vocabularies."""
+    g = torch.Generator().manual_seed(31)
+    M, V = 48, WN18RR_V
+    logits = torch.randn(M, V, generator=g) * 0.55
+    logits[::5] *= 4
+    logits[3, 100:140] = logits[3].max() + 0.25       # a run of equal logits across the nucleus boundary
+    noise = torch.empty(M, V).exponential_(1, generator=g) if T > 0 else None
+    conf, x0 = _sample_hip(lib, logits, T, top_p, top_k, _mode(margin, negent), noise)
+    # (1) against the nucleus rule evaluated exactly (oracle.exact_nucleus: prefix sums in float64): every row
+    with O.exact_nucleus():
+        rc, rx = O.sample_tokens(logits, temperature=T, top_p=top_p, top_k=top_k, margin_confidence=margin,
+                                 neg_entropy=negent, noise=noise, stable_ties=True)
+    assert torch.equal(x0, rx)
+    np.testing.assert_allclose(conf.numpy(), rc.numpy(), rtol=3e-5, atol=1e-6)
+    # (2) against the reference's fp32 arithmetic: every row except those whose exact cumulative mass passes within 1e-5
+    # of top_p at a token that matters (p > 1e-4) -- there the REFERENCE's kept set is decided by the rounding of its
+    # fp32 softmax normaliser over 41 066 terms (row 16 at T = 0.1: the first 39 tokens hold 0.8999976 of the mass,
+    # torch's CPU fp32 softmax makes it 0.9000022 and keeps 39; the exact answer, and the kernel's, is 40).
+    rc, rx = O.sample_tokens(logits, temperature=T, top_p=top_p, top_k=top_k, margin_confidence=margin,
+                             neg_entropy=negent, noise=noise, stable_ties=True)
+    ok = torch.ones(M, dtype=torch.bool)
+    if top_p is not None and T > 0:
+        ps = torch.sort(torch.softmax(logits.double() / T, -1), descending=True).values
+        gap, at = (torch.cumsum(ps, -1) - top_p).abs().min(-1)
+        ok = ~((gap < 1e-5) & (ps.gather(1, at[:, None])[:, 0] > 1e-4))
+        assert int((~ok).sum()) <= 2
+    assert torch.equal(x0[ok], rx[ok])
+    np.testing.assert_allclose(conf.numpy()[ok], rc.numpy()[ok], rtol=3e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("T,top_p,top_k", [(0.1, 0.9, None), (0.5, 0.9, None), (1.0, None, 40), (0.0, 0.9, None)])
+def test_sample_bigv_equals_lds_kernel_bit_for_bit(lib, mode, T, top_p, top_k):
+    """Same program, other row storage: a 30 000-wide row padded to 41 066 columns with logits that carry no mass
+    (-1e30) must give the LDS-resident kernel's conf / x0 on the unpadded row, bit for bit."""
+    g = torch.Generator().manual_seed(32)
+    M, Vs, V = 64, 30000, WN18RR_V
+    small = torch.randn(M, Vs, generator=g) * 0.6
+    small[::4] *= 5
+    small[1, 7:19] = small[1].max() + 0.5
+    big = torch.full((M, V), -1e30)
+    big[:, :Vs] = small
+    ns = torch.empty(M, Vs).exponential_(1, generator=g) if T > 0 else None
+    nb = None
+    if ns is not None:
+        nb = torch.ones(M, V)
+        nb[:, :Vs] = ns
+    c0, x0 = _sample_hip(lib, small, T, top_p, top_k, mode, ns)
+    c1, x1 = _sample_hip(lib, big, T, top_p, top_k, mode, nb)
+    assert torch.equal(x0, x1)
+    assert torch.equal(c0, c1)
+
+
+def test_sample_bigv_needs_its_workspace(lib):
+    """No entry point allocates: without a registered row workspace a V > 32768 call is refused with the size it needs
+    (the ctypes binding registers one by itself; this calls underneath it)."""
+    H = _hip()
+    raw = lib.dark_sample_rows.__wrapped__
+    M, V = 4, WN18RR_V
+    logits = torch.randn(M, V, device=DEV)
+    conf = torch.zeros(M, device=DEV)
+    x0 = torch.zeros(M, dtype=torch.long, device=DEV)
+    H.check(lib.dark_sampler_set_row_workspace(None, 0))
+    H._row_ws.clear()
+    rc = raw(H.ptr(logits), V, M, V, 0.0, -1.0, 0, 0, None, 0, H.ptr(conf), H.ptr(x0), _s())
+    assert rc == H.DARK_ERR_ARG and b"dark_sampler_set_row_workspace" in lib.dark_hip_last_error()
+    small = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    H.check(lib.dark_sampler_set_row_workspace(H.ptr(small), small.numel()))
+    rc = raw(H.ptr(logits), V, M, V, 0.0, -1.0, 0, 0, None, 0, H.ptr(conf), H.ptr(x0), _s())
+    assert rc == H.DARK_ERR_ARG
+    assert lib.dark_sampler_set_row_workspace(H.ptr(small), 0) == H.DARK_ERR_ARG
+    H.check(lib.dark_sampler_set_row_workspace(None, 0))
+    H.check(lib.dark_sample_rows(H.ptr(logits), V, M, V, 0.0, -1.0, 0, 0, None, 0, H.ptr(conf), H.ptr(x0), _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(x0.cpu(), logits.cpu().argmax(-1))
+
+
 def test_sample_rows_kept_set_matches_top_p(lib):
     """Property at full size: with noise concentrated on one token, x0 must be that token iff it survives
     the nucleus filter of the oracle."""
