@@ -140,7 +140,12 @@ static int lm_head_rows(const dark_model_desc* m, const void* hidden, const int3
   const size_t need = align_up((size_t)M * m->d * esize(m->dtype), 256);
   DARK_CHECK_ARG(ws_bytes >= need, "lm_head_rows: workspace %zu < required %zu bytes", ws_bytes, need);
   DARK_TRY(launch_rmsnorm(m->dtype, m->resid_dtype, hidden, m->final_norm, workspace, src_rows, n_src, M, m->d, m->rms_eps, st));
-  DARK_TRY(launch_gemm(m->dtype, EPI_F32, workspace, m->lm_head, nullptr, logits, M, m->vocab, m->d, ldl, st));
+  // A vocabulary that is not a multiple of four (DBpedia50: 25 427, WN18RR: 41 066) on a row stride that leaves room:
+  // the GEMM runs over the next multiple of four -- the extra columns come from the zero rows that pad lm_head and land
+  // in the row's own padding -- so that the persistent kernel's 16-byte logit stores apply (they need whole pieces).
+  const int v4 = (m->vocab + 3) & ~3;
+  const int n_gemm = (ldl >= v4 && m->vocab_pad >= v4) ? v4 : m->vocab;
+  DARK_TRY(launch_gemm(m->dtype, EPI_F32, workspace, m->lm_head, nullptr, logits, M, n_gemm, m->d, ldl, st));
   return DARK_OK;
 }
 

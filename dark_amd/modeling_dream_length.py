@@ -172,8 +172,9 @@ class HipState:
         if self.head_ws is None or self.head_ws.numel() < M * self.cfg.hidden_size * self.pk.elem + 256:
             self.head_ws = torch.empty(M * self.cfg.hidden_size * self.pk.elem + 256, dtype=torch.uint8,
                                        device=self.pk.device)
-        if self.logits is None or self.logits.numel() < M * self.cfg.vocab_size:
-            self.logits = torch.empty(M * self.cfg.vocab_size, dtype=torch.float32, device=self.pk.device)
+        ldl = (self.cfg.vocab_size + 3) & ~3
+        if self.logits is None or self.logits.numel() < M * ldl:
+            self.logits = torch.empty(M * ldl, dtype=torch.float32, device=self.pk.device)
 
     def forward_hidden(self, x, pos, key_mask) -> torch.Tensor:
         self.rows_valid = False
@@ -219,6 +220,18 @@ class HipState:
                                               V, self._s()))
         return self.logits[:M * V].view(M, V)
 
+    def head_rows_padded(self, src_rows: Optional[torch.Tensor], M: int, hidden: Optional[torch.Tensor] = None):
+        """head_rows for the sampler: rows on a stride of the next multiple of four floats, so that the head GEMM's and
+        the sampler's 16-byte accesses apply to vocabularies like 25 427 and 41 066 too.  Returns (buffer, stride)."""
+        V = self.cfg.vocab_size
+        ldl = (V + 3) & ~3
+        self._ensure_head(M)
+        hidden = self.hidden if hidden is None else hidden
+        _hip.check(self.lib.dark_lm_head_rows(self.pk.ref, _hip.ptr(hidden), _hip.ptr(src_rows), M,
+                                              _hip.ptr(self.head_ws), self.head_ws.numel(), _hip.ptr(self.logits),
+                                              ldl, self._s()))
+        return self.logits, ldl
+
     def head_all_rows(self) -> torch.Tensor:
         return self.head_rows(None, self.B * self.N)
 
@@ -259,13 +272,14 @@ class HipState:
                 self.head_stats_event = torch.cuda.Event()
                 self.head_stats_event.record(torch.cuda.current_stream(self.pk.device))
             return conf, x0
-        logits = self.head_rows(None, M, self.hidden_rows) if self.rows_valid else self.head_rows(self.src_rows, M)
+        logits, ldl = (self.head_rows_padded(None, M, self.hidden_rows) if self.rows_valid
+                       else self.head_rows_padded(self.src_rows, M))
         if philox is not None:
-            _hip.check(self.lib.dark_sample_rows_philox(_hip.ptr(logits), V, M, V, float(temperature), float(top_p),
+            _hip.check(self.lib.dark_sample_rows_philox(_hip.ptr(logits), ldl, M, V, float(temperature), float(top_p),
                                                         int(top_k), int(conf_mode), philox[0], philox[1], philox[2],
                                                         _hip.ptr(conf), _hip.ptr(x0), self._s()))
             return conf, x0
-        _hip.check(self.lib.dark_sample_rows(_hip.ptr(logits), V, M, V, float(temperature), float(top_p),
+        _hip.check(self.lib.dark_sample_rows(_hip.ptr(logits), ldl, M, V, float(temperature), float(top_p),
                                              int(top_k), int(conf_mode), _hip.ptr(noise),
                                              noise.stride(0) if noise is not None else 0, _hip.ptr(conf),
                                              _hip.ptr(x0), self._s()))

@@ -118,7 +118,9 @@ int dark_forward_hidden_rows(const dark_model_desc* m, int B, int N, const int32
  * restricted to the rows the sampler consumes, including the logit shift of
  * generation_utils.py:496 when `src_rows` comes from dark_mask_rows.
  *   src_rows [M] int32 row ids into `hidden`, or NULL for rows 0..M-1
- *   logits   [M, ldl] fp32 OUT (columns >= V untouched) */
+ *   logits   [M, ldl] fp32 OUT.  When V is not a multiple of four and ldl >= ((V + 3) & ~3), the columns up to that
+ *            multiple are written too (with the zero logits of lm_head's zero padding rows), so that 16-byte
+ *            stores apply; every other column >= V is untouched */
 int dark_lm_head_rows(const dark_model_desc* m, const void* hidden, const int32_t* src_rows, int M,
                       void* workspace, size_t workspace_bytes, float* logits, int64_t ldl, void* stream);
 

@@ -4,6 +4,7 @@
   3h DBpedia50 vocabulary (V=25427), B=1024 abd, 32 steps, bf16       (one GPU's share; head NOT vocab-sharded)
   4  N=128 (64 masks/row), 12 layers, 12 heads (hd=64), B=1024/GPU, 32 steps, bf16
   5  RL rollout: T=0.5, top_p=0.9, 32 steps, 4 trajectories per query, B=2048/GPU, bf16 (custom_grpo2.py:605-634)
+  wn WN18RR vocabulary (V=41066: the sampler's rows live in the registered workspace), B=1024 abd, 32 steps, bf16
 One JSON line per config: sequences/s and the per-kernel split from HIP events is left to rocprofv3."""
 import argparse
 import json
@@ -62,6 +63,11 @@ def main():
         ids = synth.make_inputs(1024, "abd", seed=1, **synth.DBPEDIA50).to(dev)
         run("3 (one GPU, unsharded head): DBpedia50 V=25427 abd B=1024 32 steps bf16", m, ids, 46, steps=32,
             temperature=0.1)
+        del m
+    if "wn" in want:
+        m = model_for(torch.bfloat16, vocab_size=synth.vocab_size(**synth.WN18RR))
+        ids = synth.make_inputs(1024, "abd", seed=1, **synth.WN18RR).to(dev)
+        run("WN18RR V=41066 abd B=1024 32 steps bf16 (row-workspace sampler)", m, ids, 46, steps=32, temperature=0.1)
         del m
     if "4" in want:
         m = model_for(torch.bfloat16, vocab_size=synth.vocab_size(**synth.FB15K237), num_hidden_layers=12,
