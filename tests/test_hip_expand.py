@@ -415,3 +415,29 @@ def test_bf16_real_shape_batch_properties():
         single = m.diffusion_generate(inputs=prompts[b].to(DEV), generation_config=_gc(50),
                                       **dict(kw, _noise_fn=lambda row, step, M, V, b=b: noise(b, step, M, V)))
         assert torch.equal(single[0].cpu(), seqs[b]), b
+
+
+def test_wn18rr_vocab_batch_equals_single_runs():
+    """The variable-length loop at WN18RR's vocabulary (V = 41 066: the sampler works from the registered row
+    workspace): 2-layer cut of the real width in bf16, 12 ragged prompts; the batched run terminates, takes edits, and
+    every row equals its single-sequence run bit for bit."""
+    cfg = DreamConfig(vocab_size=synth.vocab_size(**synth.WN18RR), num_hidden_layers=2, mask_token_id=MASK,
+                      pad_token_id=END)
+    m = DreamModel(cfg)
+    m.load_state_dict(synth.boost_edit_tokens(synth.make_weights(cfg, seed=0), 8.0, 7.0), strict=True)
+    m = m.to(DEV).to(torch.bfloat16)
+    prompts = (synth.make_var_inputs(6, "abd", 6, seed=7, **synth.WN18RR)
+               + synth.make_var_inputs(6, "ded", 8, seed=8, **synth.WN18RR))
+    noise = _seeded_noise(23)
+    kw = dict(temperature=0.5, alg="entropy", alg_temp=0, top_p=0.9, number_transfer_tokens=1, _noise_fn=noise)
+    out = m.diffusion_generate_batch([p.to(DEV) for p in prompts], generation_config=_gc(40),
+                                     return_dict_in_generate=True, output_history=True, **kw)
+    seqs = out.sequences.cpu()
+    assert seqs.shape == (12, 40) and bool(((seqs >= 0) & (seqs < cfg.vocab_size)).all())
+    for b in range(12):
+        last = out.history[b][-1].cpu()
+        assert torch.equal(seqs[b, :last.numel()], last)
+    for b in (0, 5, 11):
+        single = m.diffusion_generate(inputs=prompts[b].to(DEV), generation_config=_gc(40),
+                                      **dict(kw, _noise_fn=lambda row, step, M, V, b=b: noise(b, step, M, V)))
+        assert torch.equal(single[0].cpu(), seqs[b]), b

@@ -84,7 +84,7 @@ def test_per_token_logps_bf16_fused(gold):
         assert err.max() < 0.12 and np.median(err) < 0.03, (c["name"], err.max(), np.median(err))
 
 
-@pytest.mark.parametrize("vocab", [512, 15080])
+@pytest.mark.parametrize("vocab", [512, 15080, 25427, 41066])
 def test_fused_logprob_equals_unfused(vocab):
     """dark_lm_head_logprob (bf16, fused) against the same head materialised with dark_lm_head_rows + a torch fp32
     log_softmax/gather of those logits, on random hidden states; also edge targets (0, V-1) and gathered rows."""
