@@ -80,6 +80,8 @@ def main():
                     help="A/B hook: 0 = the library's choice, 1 = 128-row GEMM kernels only, 2 / 4 = the persistent 256x256 "
                          "kernel (plain / staggered) wherever it supports the shape; 6 / 7 / 11 = the library's choice "
                          "without the down_proj routing / without the q/k/v routing / with o_proj on the persistent kernel")
+    ap.add_argument("--sampler-single-stage", action="store_true",
+                    help="A/B: the single-stage sampler kernel only (default: the two-stage form where it applies)")
     ap.add_argument("--residual-fp32", action="store_true",
                     help="A/B: carry the bf16 model's residual stream in fp32 (default: the model dtype, as the "
                          "reference's bf16 model does)")
@@ -117,6 +119,7 @@ def main():
     dispatch.FORCE_COLLECTIVES = bool(args.force_dist)
     lib = _hip.load()
     _hip.check(lib.dark_dbg_set_gemm_variant(args.gemm_variant))
+    _hip.check(lib.dark_dbg_set_sampler_stages(1 if args.sampler_single_stage else 0))
     cfg = DreamConfig(vocab_size=synth.vocab_size(**synth.FB15K237), mask_token_id=synth.MASK,
                       pad_token_id=synth.END)
     weights = synth.make_weights(cfg, seed=0)

@@ -133,6 +133,7 @@ SIGNATURES = {
     "dark_dbg_gemm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                 C.c_int, C.c_int64, C.c_void_p]),
     "dark_dbg_set_gemm_variant": (C.c_int, [C.c_int]),
+    "dark_dbg_set_sampler_stages": (C.c_int, [C.c_int]),
     "dark_dbg_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dark_head_sample_workspace_bytes": (C.c_size_t, [C.POINTER(ModelDesc), C.c_int]),

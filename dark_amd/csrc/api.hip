@@ -453,6 +453,11 @@ int dark_sample_rows_philox(const float* logits, int64_t ldl, int M, int V, floa
 }
 
 int dark_sampler_set_row_workspace(void* ptr, size_t bytes) { return set_sampler_row_workspace(ptr, bytes); }
+int dark_dbg_set_sampler_stages(int stages) {
+  DARK_CHECK_ARG(stages == 0 || stages == 1, "set_sampler_stages: %d (0 = automatic, 1 = single-stage)", stages);
+  set_sampler_stages(stages);
+  return DARK_OK;
+}
 
 int dark_philox_exponential(uint64_t seed, uint64_t offset, uint32_t nthreads, uint64_t numel, float* out,
                             void* stream) {

@@ -250,6 +250,7 @@ int launch_shard_row_max(const float* logits, int64_t ldl, int M, int Vs, float 
 int launch_shard_partials(const float* logits, int64_t ldl, int M, int Vs, int col0, float temperature,
                           const float* mx, void* parts, hipStream_t st);
 int set_sampler_row_workspace(void* ptr, size_t bytes);
+void set_sampler_stages(int v);
 int launch_sample_from_shards(const void* parts, int64_t ldp, int S, int M, int V, float temperature, float top_p, int top_k,
                               int conf_mode, const float* mx, const float* noise, int64_t ldn, uint64_t seed,
                               uint64_t offset, uint32_t nthreads, float* conf, int64_t* x0, uint8_t* flags,

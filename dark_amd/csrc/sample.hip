@@ -87,6 +87,7 @@ struct Scratch {
   unsigned long long above;
 };
 
+template <int NT = ST>
 __device__ __forceinline__ float block_max(float v, Scratch* s, int tid) {
   v = wave_max(v);
   __syncthreads();
@@ -94,9 +95,10 @@ __device__ __forceinline__ float block_max(float v, Scratch* s, int tid) {
   __syncthreads();
   float r = s->f32a[0];
 #pragma unroll
-  for (int w = 1; w < ST / 64; ++w) r = fmaxf(r, s->f32a[w]);
+  for (int w = 1; w < NT / 64; ++w) r = fmaxf(r, s->f32a[w]);
   return r;
 }
+template <int NT = ST>
 __device__ __forceinline__ uint32_t block_max_u32(uint32_t v, Scratch* s, int tid) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
@@ -105,9 +107,10 @@ __device__ __forceinline__ uint32_t block_max_u32(uint32_t v, Scratch* s, int ti
   __syncthreads();
   uint32_t r = s->u32[0];
 #pragma unroll
-  for (int w = 1; w < ST / 64; ++w) r = max(r, s->u32[w]);
+  for (int w = 1; w < NT / 64; ++w) r = max(r, s->u32[w]);
   return r;
 }
+template <int NT = ST>
 __device__ __forceinline__ double block_sum(double v, Scratch* s, int tid) {
   v = wave_sum(v);
   __syncthreads();
@@ -115,9 +118,10 @@ __device__ __forceinline__ double block_sum(double v, Scratch* s, int tid) {
   __syncthreads();
   double r = s->f64a[0];
 #pragma unroll
-  for (int w = 1; w < ST / 64; ++w) r += s->f64a[w];
+  for (int w = 1; w < NT / 64; ++w) r += s->f64a[w];
   return r;
 }
+template <int NT = ST>
 __device__ __forceinline__ void block_sum2(double& a, double& b, Scratch* s, int tid) {
   a = wave_sum(a);
   b = wave_sum(b);
@@ -127,8 +131,9 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, Scratch* s, int
   a = s->f64a[0];
   b = s->f64b[0];
 #pragma unroll
-  for (int w = 1; w < ST / 64; ++w) { a += s->f64a[w]; b += s->f64b[w]; }
+  for (int w = 1; w < NT / 64; ++w) { a += s->f64a[w]; b += s->f64b[w]; }
 }
+template <int NT = ST>
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, Scratch* s, int tid) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -137,10 +142,11 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
   __syncthreads();
   unsigned long long r = 0;
 #pragma unroll
-  for (int w = 0; w < ST / 64; ++w) r += s->u64[w];
+  for (int w = 0; w < NT / 64; ++w) r += s->u64[w];
   return r;
 }
 
+template <int NT = ST>
 __device__ __forceinline__ void block_sum2_u64(unsigned long long& a, unsigned long long& b, Scratch* s, int tid) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
@@ -149,7 +155,7 @@ __device__ __forceinline__ void block_sum2_u64(unsigned long long& a, unsigned l
   __syncthreads();
   a = 0; b = 0;
 #pragma unroll
-  for (int w = 0; w < ST / 64; ++w) { a += s->u64[w]; b += s->u64b[w]; }
+  for (int w = 0; w < NT / 64; ++w) { a += s->u64[w]; b += s->u64b[w]; }
 }
 
 // Wave 0 scans `nbin` weight bins in the order first = bin `start`, step `dir` (the descending-logit order)
@@ -229,6 +235,7 @@ __device__ bool select_crossing(const float* row, int V, float mx, unsigned long
 // Exact resolution among c gathered candidates (keys cand[], fixed-point masses cfx[]) that form a contiguous
 // range of the descending order with mass A strictly above it: tau = the largest key whose inclusive
 // cumulative mass exceeds T.  Returns 1 and *tau / *above (mass of keys > tau) / *n_tau (multiplicity), or 0.
+template <int NT = ST>
 __device__ int resolve_candidates(const uint32_t* cand, const unsigned long long* cfx, int c, unsigned long long A,
                                   unsigned long long T, Scratch* s, int tid, uint32_t* tau,
                                   unsigned long long* above, int* n_tau) {
@@ -246,11 +253,11 @@ __device__ int resolve_candidates(const uint32_t* cand, const unsigned long long
     }
     for (int i = c4; i < c; ++i) S += cand[i] >= kj ? cfx[i] : 0ull;
   }
-  const uint32_t best = block_max_u32((own && S > T) ? kj : 0u, s, tid);
+  const uint32_t best = block_max_u32<NT>((own && S > T) ? kj : 0u, s, tid);
   if (best == 0) return 0;
   // mass strictly above tau and the multiplicity of tau, again one candidate per thread
   unsigned long long ab = (own && kj > best) ? fj : 0ull, nt = (own && kj == best) ? 1ull : 0ull;
-  block_sum2_u64(ab, nt, s, tid);
+  block_sum2_u64<NT>(ab, nt, s, tid);
   *tau = best;
   *above = A + ab;
   *n_tau = (int)nt;
@@ -480,6 +487,207 @@ __device__ void list_tail_wave(const uint32_t* cand, const unsigned long long* c
     *x0_out = (int64_t)bi;
   }
   if (conf_mode == DARK_CONF_PROB && my_e > 0.f && my_idx == bi) *conf_out = my_p;  // after lane 0's store
+}
+
+// ---- two-stage sampler, first stage: the head path with the row in REGISTERS.
+// sample_kernel keeps a row in LDS (60 KB at V = 15 080: two workgroups per CU), which its fallback paths need; the
+// path that peaked rows take -- masses, the candidates within HEAD_RANGE of the maximum, crossing / softmax /
+// confidence / draw over that list -- reads every element exactly twice and needs no row storage beyond the registers
+// of 256 threads (NV4 float4 each).  The arithmetic is sample_kernel's: same temperature division, same maximum,
+// integer masses, the same candidate records, list_tail_wave for <= 64
+// candidates and the operations of sample_row's list mode for up to one candidate per thread; every sum is an integer
+// sum or a double sum of floats of like magnitude (exact), so conf / x0 are bit-identical whatever the order.  A row
+// this stage cannot finish (more than SH candidates, or candidates that do not hold top_p of the mass) is marked
+// x0 = -1 for the second stage (sample_kernel over all M rows: a workgroup whose row is done returns at once; such a
+// launch costs 12 us at M = 16 896), untouched otherwise.  No state outlives a launch.
+constexpr int SH = 256;
+
+template <int NV4>
+__global__ __launch_bounds__(SH) void sample_head_kernel(const float* __restrict__ logits, int64_t ldl, int V,
+                                                         float temperature, float top_p, int conf_mode,
+                                                         const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
+                                                         float* __restrict__ conf, int64_t* __restrict__ x0) {
+  __shared__ uint32_t cand[SH];
+  __shared__ unsigned long long cfx[SH];
+  __shared__ int cidx[SH];
+  __shared__ Scratch sc;
+  Scratch* s = &sc;
+  const int tid = threadIdx.x, m = blockIdx.x;
+  auto give_up = [&]() {  // block-uniform: x0 = -1 hands the row to the second stage
+    if (tid == 0) x0[m] = -1;
+  };
+  if (tid == 0) s->ncand = 0;
+
+  // 1. the row and its maximum; the division by the temperature (generation_utils.py:60-61) follows below
+  const float* lr = logits + (int64_t)m * ldl;
+  const int v4 = V >> 2;
+  float4 r[NV4];
+#pragma unroll
+  for (int u = 0; u < NV4; ++u) {
+    const int i = tid + u * SH;
+    r[u] = i < v4 ? *(const float4*)(lr + 4 * i) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  }
+  float tail = (4 * v4 + tid < V) ? lr[4 * v4 + tid] : -INFINITY;   // V % 4 elements, threads 0..2
+  // The maximum of the RAW row first: division by a positive temperature is monotone and correctly rounded, so
+  // max(l / T) = max(l) / T bit for bit, and whether a row is flat can be told before paying for V divisions.
+  float mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < NV4; ++u) mx = fmaxf(fmaxf(mx, fmaxf(r[u].x, r[u].y)), fmaxf(r[u].z, r[u].w));
+  mx = block_max<SH>(fmaxf(mx, tail), s, tid);
+
+  // 2. flat rows leave here, before the expensive passes: more than SH float4 pieces that hold an element within
+  // (about) HEAD_RANGE of the maximum mean more than SH candidates.  A heuristic may err either way without touching
+  // a result: both stages compute the same function.  (The second stage reads the row again: +5 % on rows like
+  // T = 0.5 on random-init logits, which this stage cannot help.)
+  {
+    const float reach = HEAD_RANGE * (temperature > 0.f ? temperature : 1.f);
+    int c4 = 0;
+#pragma unroll
+    for (int u = 0; u < NV4; ++u)
+      c4 += fmaxf(fmaxf(r[u].x, r[u].y), fmaxf(r[u].z, r[u].w)) - mx > -reach;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c4 += __shfl_xor(c4, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) s->i32[tid >> 6] = c4;
+    __syncthreads();
+    c4 = 0;
+#pragma unroll
+    for (int w = 0; w < SH / 64; ++w) c4 += s->i32[w];
+    if (c4 > SH) { give_up(); return; }
+  }
+  if (temperature > 0.f) {
+#pragma unroll
+    for (int u = 0; u < NV4; ++u) {
+      r[u].x = r[u].x / temperature; r[u].y = r[u].y / temperature;
+      r[u].z = r[u].z / temperature; r[u].w = r[u].w / temperature;
+    }
+    tail = tail / temperature;
+    mx = mx / temperature;
+  }
+
+  // 3. masses and the candidate records
+  unsigned long long zl = 0, hl = 0;      // row mass; mass of the candidates this thread recorded
+  int mine = 0;  // a thread records at most 8 of its 64 elements, then poisons the count (one LDS address serves them all)
+  auto element = [&](float l, int i) {
+    const unsigned long long fx = mass_fx_nb(l, mx);
+    zl += fx;
+    if (l - mx > -HEAD_RANGE) {
+      if (mine < 8) {
+        const int slot = atomicAdd(&s->ncand, 1);
+        if (slot < SH) { cand[slot] = fkey(l); cfx[slot] = fx; cidx[slot] = i; hl += fx; }
+      } else if (mine == 8) {
+        atomicAdd(&s->ncand, SH + 1);  // the candidate set is incomplete: the row goes to the second stage
+      }
+      ++mine;
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < NV4; ++u) {
+    // (a wave whose 256 elements all lie below the mass range -- most of a peaked row -- skips their exp chains: they
+    // would add zeros)
+    const float top4 = fmaxf(fmaxf(r[u].x, r[u].y), fmaxf(r[u].z, r[u].w));
+    if (__any(top4 - mx > -MASS_RANGE)) {
+      element(r[u].x, 4 * (tid + u * SH));
+      element(r[u].y, 4 * (tid + u * SH) + 1);
+      element(r[u].z, 4 * (tid + u * SH) + 2);
+      element(r[u].w, 4 * (tid + u * SH) + 3);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (one float4 at a time: interleaving all the exp chains costs registers)
+  }
+  element(tail, 4 * v4 + tid);
+  block_sum2_u64<SH>(zl, hl, s, tid);  // (its barriers also publish the candidates)
+  const unsigned long long T = (unsigned long long)((double)top_p * (double)zl);  // floor, as nucleus_crossing
+  const int c = s->ncand;
+  if (c < 1 || c > SH || !(hl > T)) { give_up(); return; }
+
+  const float* qr = noise + (int64_t)m * ldn;
+  const unsigned long long q0 = (unsigned long long)m * V;
+  if (c <= 64) {  // wave 0 finishes the row exactly as sample_kernel's head path does
+    if (tid < 64) list_tail_wave(cand, cfx, cidx, c, T, mx, V, temperature, conf_mode, qr, pn, q0, tid, conf + m, x0 + m);
+    return;
+  }
+
+  // 4. up to one candidate per thread: sample_row's list mode, operation for operation
+  uint32_t tau = 0;
+  unsigned long long above = 0;
+  int n_tau = 0;
+  if (resolve_candidates<SH>(cand, cfx, c, 0ull, T, s, tid, &tau, &above, &n_tau) <= 0) { give_up(); return; }
+  const unsigned long long fxt = mass_fx(fkey_inv(tau), mx);
+  const unsigned long long t_keep = fxt ? (T - above) / fxt + 1ull : (unsigned long long)n_tau;
+  int my_idx = 0;
+  float my_e = 0.f;
+  if (tid < c) {
+    const uint32_t kj = cand[tid];
+    my_idx = cidx[tid];
+    bool keep = kj > tau;
+    if (kj == tau) {
+      keep = true;
+      if (t_keep < (unsigned long long)n_tau) {  // only the first t_keep (by index) of the equal logits stay
+        unsigned long long rank = 0;
+        for (int i = 0; i < c; ++i) rank += (cand[i] == tau && cidx[i] < my_idx);
+        keep = rank < t_keep;
+      }
+    }
+    if (keep) my_e = exp_neg(fkey_inv(kj) - mx);
+  }
+  const float Zf = (float)block_sum<SH>((double)my_e, s, tid);
+  double ps = 0.0, ent = 0.0;
+  float t1 = -INFINITY, t2 = -INFINITY, bestp = -INFINITY, my_p = 0.f;
+  int besti = 0x7fffffff;
+  if (my_e > 0.f) {
+    my_p = my_e / Zf;
+    ps = (double)my_p;
+    if (conf_mode == DARK_CONF_NEG_ENTROPY) ent = (double)(my_p * log_pos(my_p + 1e-10f));
+    t1 = my_p;
+    bestp = my_p;
+    besti = my_idx;
+  }
+  block_sum2<SH>(ps, ent, s, tid);
+  const float psum = (float)ps;
+  const float entropy = (float)ent;
+  if (temperature > 0.f) {
+    bestp = -INFINITY;
+    besti = 0x7fffffff;
+    if (my_p > 0.f) {
+      bestp = (my_p / psum) / (pn.nthreads ? philox_exponential(pn, q0 + my_idx) : qr[my_idx]);
+      besti = my_idx;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bestp, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > bestp || (ov == bestp && oi < besti)) { bestp = ov; besti = oi; }
+    const float o1 = __shfl_xor(t1, o, 64), o2 = __shfl_xor(t2, o, 64);
+    const float n1 = fmaxf(t1, o1), n2 = fmaxf(fminf(t1, o1), fmaxf(t2, o2));
+    t1 = n1; t2 = n2;
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) {
+    s->f32a[tid >> 6] = bestp; s->i32[tid >> 6] = besti;
+    s->f32b[tid >> 6] = t1; s->f32c[tid >> 6] = t2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float bv = s->f32a[0]; int bi = s->i32[0];
+    float a1 = s->f32b[0], a2 = s->f32c[0];
+    for (int w = 1; w < SH / 64; ++w) {
+      const float ov = s->f32a[w]; const int oi = s->i32[w];
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      const float o1 = s->f32b[w], o2 = s->f32c[w];
+      const float n1 = fmaxf(a1, o1), n2 = fmaxf(fminf(a1, o1), fmaxf(a2, o2));
+      a1 = n1; a2 = n2;
+    }
+    if (bi < 0 || bi >= V) bi = 0;
+    if (a2 < 0.f) a2 = 0.f;
+    conf[m] = conf_mode == DARK_CONF_NEG_ENTROPY ? entropy : (conf_mode == DARK_CONF_MARGIN ? a1 - a2 : 0.f);
+    x0[m] = (int64_t)bi;
+    s->bin = bi;
+  }
+  if (conf_mode == DARK_CONF_PROB) {  // the probability of the winner lives in its owner thread
+    __syncthreads();
+    if (my_e > 0.f && my_idx == s->bin) conf[m] = my_p;
+  }
 }
 
 // GROW = false: the row lives in LDS (V <= SAMPLE_LDS_MAX_V, every vocabulary the benchmarked configs use).
@@ -767,7 +975,10 @@ __global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ lo
                                                     const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
                                                     float* __restrict__ conf, int64_t* __restrict__ x0,
                                                     const int32_t* __restrict__ row_ids,
-                                                    const int32_t* __restrict__ n_dev) {
+                                                    const int32_t* __restrict__ n_dev, int second_stage) {
+  // second_stage (of the two-stage sampler): only the rows sample_head_kernel marked with x0 = -1; the other workgroups
+  // return at once (12 us for 16 896 of them)
+  if (second_stage && x0[blockIdx.x] != -1) return;
   sample_row<false>(logits, ldl, V, temperature, top_p, top_k, conf_mode, noise, ldn, pn, conf, x0, row_ids, n_dev, nullptr);
 }
 
@@ -785,6 +996,9 @@ namespace {
 struct RowWorkspace { std::atomic<void*> ptr{nullptr}; std::atomic<size_t> bytes{0}; };
 RowWorkspace g_row_ws[DARK_MAX_DEVICES];
 }  // namespace
+
+static std::atomic<int> g_sampler_stages{0};   // 0 = automatic, 1 = single-stage only (A/B and tests)
+void set_sampler_stages(int v) { g_sampler_stages.store(v, std::memory_order_relaxed); }
 
 int set_sampler_row_workspace(void* ptr, size_t bytes) {
   int dev = 0;
@@ -857,8 +1071,24 @@ int launch_sample_indexed(const float* logits, int64_t ldl, int M, int V, float 
   const int smem = ((V + 3) & ~3) * 4 + NLIN * 8 + CAND_CAP * 16 + (int)sizeof(Scratch);
   static SmemOptIn optin;
   DARK_TRY(optin.ensure((const void*)sample_kernel, smem, st));
+  // Two-stage form (see sample_head_kernel): a plain [M, V] call with the nucleus filter on and top-k off, rows that
+  // load 16 bytes a lane and fit the first stage's registers.
+  if (g_sampler_stages.load(std::memory_order_relaxed) != 1 && !row_ids && !n_dev && top_p >= 0.f && top_p < 1.f &&
+      !(top_k > 0 && top_k < V) && (ldl & 3) == 0 && ((uintptr_t)logits & 15) == 0 && (V >> 2) <= 26 * SH) {
+    if ((V >> 2) <= 16 * SH)
+      hipLaunchKernelGGL(sample_head_kernel<16>, dim3(M), dim3(SH), 0, st, logits, ldl, V, temperature, top_p, conf_mode,
+                         noise, ldn, pn, conf, x0);
+    else
+      hipLaunchKernelGGL(sample_head_kernel<26>, dim3(M), dim3(SH), 0, st, logits, ldl, V, temperature, top_p, conf_mode,
+                         noise, ldn, pn, conf, x0);
+    DARK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sample_kernel, dim3(M), dim3(ST), smem, st, logits, ldl, V, temperature, top_p, top_k, conf_mode,
+                       noise, ldn, pn, conf, x0, row_ids, n_dev, 1);
+    DARK_CHECK_LAUNCH();
+    return DARK_OK;
+  }
   hipLaunchKernelGGL(sample_kernel, dim3(M), dim3(ST), smem, st, logits, ldl, V, temperature, top_p, top_k,
-                     conf_mode, noise, ldn, pn, conf, x0, row_ids, n_dev);
+                     conf_mode, noise, ldn, pn, conf, x0, row_ids, n_dev, 0);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }

@@ -467,6 +467,10 @@ int dark_dbg_gemm_resid_norm(const void* A, const void* W, float* hidden, const 
  *   kernel / with o_proj there too (the in-loop A/Bs recorded in DESIGN.md);
  *   16 + p = timing probe p of gemm_bf16_s256 (WRONG results unless p = 8 or 9: per-phase cycle sums). */
 int dark_dbg_set_gemm_variant(int variant);
+/* A/B and test hook of the sampler: 0 = automatic (plain calls with the nucleus filter on, top-k off and V <= 26 624
+ * run the two-stage form: sample_head_kernel with the row in registers, then sample_kernel for the rows it marked),
+ * 1 = the single-stage kernel only.  Results are bit-identical either way (tests/test_hip_kernels.py). */
+int dark_dbg_set_sampler_stages(int stages);
 int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                        const uint8_t* key_mask, void* out, int B, int N, int H, int HD, int max_pos,
                        void* stream);

@@ -445,6 +445,61 @@ def test_sample_bigv_needs_its_workspace(lib):
     assert torch.equal(x0.cpu(), logits.cpu().argmax(-1))
 
 
+@pytest.mark.parametrize("V,ld_pad", [(15080, 0), (15082, 2), (25427, 1), (16384, 0), (26624, 0), (1000, 0)])
+def test_two_stage_sampler_equals_single_stage_bit_for_bit(lib, V, ld_pad):
+    """sample_head_kernel (row in registers) + sample_kernel on the rows it marks, against sample_kernel alone: conf
+    and x0 bit for bit.  Rows of every kind in one launch: peaked (<= 64 candidates: wave tail), 65..256 candidates
+    (block list mode of the first stage), more (second stage), flat (early exit), runs of equal logits across the
+    nucleus boundary, all-equal rows, a NaN, -inf entries; every confidence mode; injected and Philox noise; T = 0;
+    top_p = 0; vocabularies with V % 4 != 0 on a padded stride (the tail elements) and the 26-float4 instance."""
+    H = _hip()
+    g = torch.Generator().manual_seed(41 + V)
+    M = 300
+    ld = V + ld_pad
+    assert ld % 4 == 0
+    base = torch.randn(M, V, generator=g)
+    scale = torch.tensor([0.3, 1.0, 3.0, 6.0, 12.0, 25.0])[torch.arange(M) % 6][:, None]
+    rows = base * scale
+    rows[7, 10:50] = rows[7].max() + 0.5          # 40 equal maxima
+    rows[8, 100:400] = rows[8].max() + 0.5        # 300 equal maxima (beyond the first stage's capacity)
+    rows[9, 3:150] = rows[9].max() + 2.0          # 147 equal maxima (block list mode)
+    rows[10] = 1.25                               # all equal
+    rows[11, 5] = float("nan")
+    rows[12, ::3] = float("-inf")
+    rows[13, V - 3:] = rows[13].max() + 4.0       # the winners sit in the tail elements
+    buf = torch.zeros(M, ld)
+    buf[:, :V] = rows
+    logits = buf.to(DEV)
+    noise = torch.empty(M, V).exponential_(1, generator=g).to(DEV)
+    conf = torch.zeros(M, device=DEV)
+    x0 = torch.zeros(M, dtype=torch.long, device=DEV)
+
+    def run(stages, T, top_p, mode, philox):
+        H.check(lib.dark_dbg_set_sampler_stages(stages))
+        conf.fill_(-7.0)
+        x0.fill_(-7)
+        if philox:
+            H.check(lib.dark_sample_rows_philox(H.ptr(logits), ld, M, V, T, top_p, 0, mode, 77, 4, 256 * 512, H.ptr(conf),
+                                                H.ptr(x0), _s()))
+        else:
+            H.check(lib.dark_sample_rows(H.ptr(logits), ld, M, V, T, top_p, 0, mode, H.ptr(noise) if T > 0 else None,
+                                         V if T > 0 else 0, H.ptr(conf), H.ptr(x0), _s()))
+        torch.cuda.synchronize()
+        return conf.cpu().view(torch.int32).clone(), x0.cpu().clone()
+
+    try:
+        for T, top_p in ((0.1, 0.9), (0.5, 0.9), (1.0, 0.95), (0.0, 0.9), (0.3, 0.0), (2.0, 0.5)):
+            for mode in (0, 1, 2):
+                for philox in ((False, True) if T > 0 else (False,)):
+                    c1, x1 = run(1, T, top_p, mode, philox)
+                    c2, x2 = run(0, T, top_p, mode, philox)
+                    assert torch.equal(x1, x2), (T, top_p, mode, philox, (x1 != x2).nonzero().flatten()[:8].tolist())
+                    assert torch.equal(c1, c2), (T, top_p, mode, philox, (c1 != c2).nonzero().flatten()[:8].tolist())
+                    assert int(x2.min()) >= 0 and int(x2.max()) < V
+    finally:
+        H.check(lib.dark_dbg_set_sampler_stages(0))
+
+
 def test_sample_rows_kept_set_matches_top_p(lib):
     """Property at full size: with noise concentrated on one token, x0 must be that token iff it survives
     the nucleus filter of the oracle."""
