@@ -451,3 +451,33 @@ def test_model_on_non_current_device():
         ids = synth.make_inputs(4, "abd", seed=3).to(dev)
         outs.append(m.diffusion_generate(ids, generation_config=_gc(), steps=4, alg="entropy", temperature=0.0).cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_lm_head_rows_padded_stride(dtype):
+    """dark_lm_head_rows on a vocabulary that is not a multiple of four (DBpedia50: 25 427): on a stride that leaves room
+    the GEMM runs over the next multiple of four (the persistent kernel's 16-byte stores) -- the first V columns are the
+    same bits as on the tight stride, the columns up to that multiple hold the zero logits of lm_head's padding rows,
+    everything beyond is untouched (include/dark_hip.h)."""
+    lib = _hip.load()
+    V = 25427
+    m = _model(dict(vocab_size=V, hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=4,
+                    num_key_value_heads=4, max_position_embeddings=64, mask_token_id=synth.MASK, pad_token_id=synth.END),
+               dtype)
+    pk = m.packed()
+    M = 2100
+    hidden = (torch.randn(M, 256, generator=torch.Generator().manual_seed(3)) * 2).to(DEV).to(pk.resid_dtype)
+    s = _hip.stream_ptr(torch.device(DEV))
+    ws_b = lib.dark_head_workspace_bytes(pk.ref, M)
+    ws = torch.empty(ws_b, dtype=torch.uint8, device=DEV)
+    outs = {}
+    for ldl in (V, V + 1, V + 5):
+        buf = torch.full((M, ldl), 7.0, dtype=torch.float32, device=DEV)
+        _hip.check(lib.dark_lm_head_rows(pk.ref, _hip.ptr(hidden), None, M, _hip.ptr(ws), ws_b, _hip.ptr(buf), ldl, s))
+        torch.cuda.synchronize()
+        outs[ldl] = buf.cpu()
+    assert bool((outs[V] != 7.0).all())
+    for ldl in (V + 1, V + 5):
+        assert torch.equal(outs[ldl][:, :V], outs[V]), ldl
+        assert bool((outs[ldl][:, V:V + 1] == 0.0).all()), "the column up to the multiple of four: zero logits"
+        assert bool((outs[ldl][:, V + 1:] == 7.0).all()), "columns beyond stay untouched"
