@@ -694,7 +694,12 @@ double s256_best_cost(int epi, int M, int N, int* cus_out);
 // 3 = timing probe: variant 2 with the main loop's LDS-DMA issue removed (wrong results); 16 + p = timing probe p of
 // gemm_bf16_s256 (gemm256.hip, wrong results): variant 4 with parts of its intervals removed; 8 / 10 = variant 4 with
 // its tile height forced to 256 / 288 / 320 rows (A/B of the instantiations; other values leave the choice automatic)
+// 1000 + t = the automatic choice with gemm_bf16_s256's TUNE = t wherever that kernel runs (results unchanged)
+void set_s256_tune(int v);
 void set_gemm_variant(int v) {
+  const bool tuned = v >= 1000;
+  set_s256_tune(tuned ? v - 1000 : 0);
+  if (tuned) v = 0;
   set_p256_nodma(v == 3);
   set_s256_probe(v >= 16 ? v - 16 : 0);
   set_s256_rows(v == 8 ? 256 : (v == 9 ? 288 : (v == 10 ? 320 : 0)));

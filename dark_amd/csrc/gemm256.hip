@@ -287,14 +287,32 @@ template <> struct StoresPerTile<EPI_F32> { static constexpr int PER_MI = 4; };
 template <> struct StoresPerTile<EPI_HEAD> { static constexpr int PER_MI = 1; };
 template <> struct StoresPerTile<EPI_RESID_H> { static constexpr int PER_MI = 2; };
 constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }  // vmcnt(n), nothing else
+// vmcnt(n) for a wave-uniform run-time n (s_waitcnt takes an immediate); LGKM0: lgkmcnt(0) as well.  n > 63 waits for 63.
+template <bool LGKM0>
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+#define DARK_W(N_) case N_: __builtin_amdgcn_s_waitcnt(LGKM0 ? (waitcnt_vm(N_) & 0xF0FF) : waitcnt_vm(N_)); break;
+#define DARK_W8(B_) DARK_W(B_) DARK_W(B_ + 1) DARK_W(B_ + 2) DARK_W(B_ + 3) DARK_W(B_ + 4) DARK_W(B_ + 5) DARK_W(B_ + 6) DARK_W(B_ + 7)
+  switch (n) {
+    DARK_W8(0) DARK_W8(8) DARK_W8(16) DARK_W8(24) DARK_W8(32) DARK_W8(40) DARK_W8(48)
+    DARK_W(56) DARK_W(57) DARK_W(58) DARK_W(59) DARK_W(60) DARK_W(61) DARK_W(62)
+    default: __builtin_amdgcn_s_waitcnt(LGKM0 ? (waitcnt_vm(63) & 0xF0FF) : waitcnt_vm(63)); break;
+  }
+#undef DARK_W8
+#undef DARK_W
+}
 }  // namespace
 
 // PROBE != 0: timing-only builds (WRONG RESULTS) that tell where an interval's time goes -- bit 0: no LDS-DMA issue in
 // the steady state, bit 1: no fragment reads after the first K-tile, bit 2: no epilogue arithmetic / stores; bit 3
-// (results stay correct): per-wave cycle sums of the interval's phases, written through `bias` as int64[grid][8 waves][6]
+// (results stay correct): per-wave cycle sums of the interval's phases, written through `bias` as int64[grid][8 waves][8]
 // = {LOAD work until its reads have returned, wait for the next K-tile's DMA, barrier wait behind LOAD, MFMA issue,
 // barrier wait behind the MFMAs, K-tiles} (s_memtime costs a few dozen cycles per sample: proportions, not absolutes).
-template <int EPI, int PROBE = 0, int MI = 8>
+// TUNE (results stay correct; A/B hooks of the interval structure, dark_dbg_set_gemm_variant(64 + TUNE)):
+//   bit 0: group 0 waits for its pieces of the next K-tile at the END of its MFMA interval instead of the end of its
+//          LOAD interval (they are first read behind the barrier that closes that MFMA interval);
+//   bit 1: s_setprio 1 for the LOAD interval;
+//   bit 2: the K-tile's DMA pieces are dealt unevenly: (TUNE >> 4) & 7 (0 = 6) a wave in group 0, the rest over group 1.
+template <int EPI, int PROBE = 0, int MI = 8, int TUNE = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                       const float* __restrict__ bias, void* __restrict__ out, int M,
                                                       int N, int K, int64_t ldo, int tilesM, int tilesN, int ntiles,
@@ -332,31 +350,111 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)o_bytes, 0x00020000);
   const unsigned kb = (unsigned)K * 2u;
   // piece = 16 rows x 64 B: lane l -> row (l >> 2), position l & 3 holds logical chunk (l & 3) ^ ((l >> 4) & 2)
-  const unsigned voff = (unsigned)(lane >> 2) * kb + (unsigned)(((lane & 3) ^ ((lane >> 4) & 2)) << 4);
+  // (PROBE bit 4, timing only, WRONG results: every DMA fetches 8 rows x 128 B -- whole cache lines -- instead of 16 rows
+  // x 64 B; the same bytes per K-tile, every line fetched once instead of as two halves one K-tile apart)
+  const unsigned voff = (PROBE & 16) ? (unsigned)(lane >> 3) * kb + (unsigned)((lane & 7) << 4)
+                                     : (unsigned)(lane >> 2) * kb + (unsigned)(((lane & 3) ^ ((lane >> 4) & 2)) << 4);
+  auto piece_off = [&](int p, int kt) -> unsigned {
+    if constexpr (PROBE & 16) return ((unsigned)p * 16u + 8u * (unsigned)(kt & 1)) * kb + (unsigned)(kt >> 1) * 128u;
+    else return (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
+  };
   // this wave's pieces of K-tile kt: A pieces first (NALO, or NALO + 1 for a hi wave), then its two W pieces
   const bool hi = wave < NHI;   // (wave-uniform)
   const int pa0 = hi ? wave * (NALO + 1) : NHI * (NALO + 1) + (wave - NHI) * NALO;   // first A piece of this wave
+  // TUNE bit 2: pieces [A 0 .. 2 MI - 1 | W 0 .. 15] dealt as C0 a wave in group 0, the rest evenly over group 1
+  constexpr int NP = 2 * MI + 16;
+  constexpr int C0 = ((TUNE >> 4) & 7) ? ((TUNE >> 4) & 7) : 6;
+  constexpr int R1 = NP - 4 * C0, B1 = R1 / 4, X1 = R1 - 4 * B1;
+  static_assert(!(TUNE & 4) || (R1 >= 0 && C0 <= 8), "TUNE: bad piece split");
+  constexpr int MAXP = C0 > B1 + 1 ? C0 : B1 + 1;
+  const int t_beg = wave < 4 ? wave * C0 : 4 * C0 + (wave - 4) * B1 + min(wave - 4, X1);
+  const int t_cnt = wave < 4 ? C0 : B1 + ((wave - 4) < X1 ? 1 : 0);
+  // counted waits with immediate operands: this wave's DMAs per K-tile take one of three values (wave-uniform)
+  constexpr int OPS_A = (TUNE & 4) ? C0 : OPSHI, OPS_B = (TUNE & 4) ? B1 + 1 : OPSLO, OPS_C = (TUNE & 4) ? B1 : OPSLO;
+  const int ops_class = (TUNE & 4) ? (wave < 4 ? 0 : ((wave - 4) < X1 ? 1 : 2)) : ((NHI > 0 && hi) ? 0 : 1);
+  // wait until at most (ops per K-tile) * (NB - 2) [+ NST behind an epilogue] vector-memory operations are outstanding
+  auto wait_batches = [&](bool with_stores, bool lgkm0) {
+#define DARK_WB(OPS_)                                                                                     \
+    {                                                                                                     \
+      if (with_stores) {                                                                                  \
+        if (lgkm0) __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2) + NST) & 0xF0FF);              \
+        else __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2) + NST));                             \
+      } else {                                                                                            \
+        if (lgkm0) __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2)) & 0xF0FF);                    \
+        else __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2)));                                   \
+      }                                                                                                   \
+    }
+    if (ops_class == 0) DARK_WB(OPS_A)
+    else if (ops_class == 1) DARK_WB(OPS_B)
+    else DARK_WB(OPS_C)
+#undef DARK_WB
+  };
   auto stage = [&](int buf, unsigned a0, unsigned w0, int kt) {
     char* base = smem + buf * S_BUF;
+    if constexpr (TUNE & 4) {
+#pragma unroll
+      for (int q = 0; q < MAXP; ++q) {
+        if (q < t_cnt) {
+          const int p = t_beg + q;
+          const bool isA = p < 2 * MI;
+          const int pp = isA ? p : p - 2 * MI;
+          const unsigned so = piece_off(pp, kt);
+          if (isA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + pp * 1024), 16, voff + (a0 + so), 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + S_OPER + pp * 1024), 16, voff + (w0 + so), 0, 0, 0);
+        }
+      }
+    } else {
     if constexpr (NHI > 0) {
       if (hi) {  // the extra A piece of the hi waves
         const int p = pa0 + NALO;
-        const unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
+        const unsigned so = piece_off(p, kt);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + p * 1024), 16, voff + (a0 + so), 0, 0, 0);
       }
     }
 #pragma unroll
     for (int q = 0; q < NALO; ++q) {
       const int p = pa0 + q;
-      const unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
+      const unsigned so = piece_off(p, kt);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + p * 1024), 16, voff + (a0 + so), 0, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int p = wave * 2 + q;
-      const unsigned so = (unsigned)p * 16u * kb + (unsigned)kt * (SBK * 2);
+      const unsigned so = piece_off(p, kt);
       // (the whole offset goes into the VGPR operand: the SGPR offset is EXCLUDED from the descriptor's bounds check)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + S_OPER + p * 1024), 16, voff + (w0 + so), 0, 0, 0);
+    }
+    }
+  };
+
+  // (TUNE bit 3) piece q of this wave's share of a K-tile, one call per DMA: q < NALO -> A piece, then the two W pieces,
+  // then the extra A piece of a hi wave; q >= this wave's count does nothing
+  constexpr int NQ = (TUNE & 4) ? MAXP : NALO + 2 + (NHI > 0 ? 1 : 0);
+  auto stage_piece = [&](int q, int buf, unsigned a0, unsigned w0, int kt) {
+    char* base = smem + buf * S_BUF;
+    if constexpr (TUNE & 4) {
+      if (q < t_cnt) {
+        const int p = t_beg + q;
+        const bool isA = p < 2 * MI;
+        const int pp = isA ? p : p - 2 * MI;
+        const unsigned so = piece_off(pp, kt);
+        if (isA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + pp * 1024), 16, voff + (a0 + so), 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + S_OPER + pp * 1024), 16, voff + (w0 + so), 0, 0, 0);
+      }
+    } else {
+      if (q < NALO) {
+        const int pp = pa0 + q;
+        const unsigned so = piece_off(pp, kt);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + pp * 1024), 16, voff + (a0 + so), 0, 0, 0);
+      } else if (q < NALO + 2) {
+        const int pp = wave * 2 + (q - NALO);
+        const unsigned so = piece_off(pp, kt);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + S_OPER + pp * 1024), 16, voff + (w0 + so), 0, 0, 0);
+      } else if (NHI > 0 && hi) {
+        const int pp = pa0 + NALO;
+        const unsigned so = piece_off(pp, kt);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(base + pp * 1024), 16, voff + (a0 + so), 0, 0, 0);
+      }
     }
   };
 
@@ -385,6 +483,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
     d_w0 = (unsigned)tn * 256u * kb;
   }
   bool probe_warm = false;  // (PROBE builds: set once the pipeline is primed)
+  auto dma_advance = [&]() {
+    d_buf = d_buf + 1 == NB ? 0 : d_buf + 1;
+    if (++d_kt == KT) {
+      d_kt = 0;
+      d_id += G;
+      if (d_id < ntiles) {
+        int tm, tn;
+        tile_of(d_id, tm, tn);
+        d_a0 = (unsigned)tm * (unsigned)TM * kb;
+        d_w0 = (unsigned)tn * 256u * kb;
+      }
+    }
+  };
   auto stage_next = [&]() {
     if constexpr (PROBE & 1) { if (probe_warm) return; }
     if (d_id < ntiles) stage(d_buf, d_a0, d_w0, d_kt);
@@ -407,7 +518,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   for (int i = 0; i < NB - 1; ++i) stage_next();
   probe_warm = true;
   // K-tile 0 has landed (this wave's pieces): NB - 2 younger batches are still in flight
-  if (NHI == 0 || !hi) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSLO * (NB - 2)));
+  if constexpr (TUNE != 0) wait_batches(false, false);
+  else if (NHI == 0 || !hi) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSLO * (NB - 2)));
   else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSHI * (NB - 2)));
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one interval behind group 0
@@ -587,7 +699,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
 
   int pm0 = 0, pn0 = 0;   // the tile whose accumulators are waiting for their epilogue
   bool pending = false;
-  long long pt[6] = {0, 0, 0, 0, 0, 0};
+  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto now = [&]() -> long long {
     if constexpr (PROBE & 8) return (long long)__builtin_readcyclecounter();
     else return 0;
@@ -598,7 +710,34 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
     for (int kt = 0; kt < KT; ++kt) {
       // ================= LOAD interval =================
       const long long t0 = now();
+      if constexpr (TUNE & 2) __builtin_amdgcn_s_setprio(1);
       if (kt == 0 && pending) epilogue(pm0, pn0);   // the partner group's MFMAs run meanwhile
+      const long long t0e = now();
+      long long t0a = 0, t0b = 0;
+      if constexpr (TUNE & 8) {
+        // fragment reads (LDS-bound: 1 KiB each at 256 B per clock, four waves at once) and DMA pieces (bound by the
+        // texture addresser: 1 KiB each at 64 B per clock) issued alternately, a DMA first, so that the two units work
+        // at the same time instead of one after the other
+        const char* as = smem + rbuf * S_BUF + a_rd;
+        const char* ws = smem + rbuf * S_BUF + w_rd;
+        const bool live = d_id < ntiles;
+        const unsigned ca0 = live ? d_a0 : 0xF0000000u, cw0 = live ? d_w0 : 0xF0000000u;
+        const int ckt = live ? d_kt : 0;
+        constexpr int NR = P_NI + MI;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+#pragma unroll
+          for (int q = (r * NQ + NR - 1) / NR; q < ((r + 1) * NQ + NR - 1) / NR; ++q) {
+            stage_piece(q, d_buf, ca0, cw0, ckt);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (r < P_NI) fw[r] = *(const bf16x8*)(ws + r * 1024);
+          else fa[r - P_NI] = *(const bf16x8*)(as + (r - P_NI) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        dma_advance();
+        t0a = t0b = now();
+      } else {
       if (!(PROBE & 2) || (!pending && kt == 0)) {
         const char* as = smem + rbuf * S_BUF + a_rd;
         const char* ws = smem + rbuf * S_BUF + w_rd;
@@ -608,8 +747,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(as + i * 1024);
       }
       __builtin_amdgcn_sched_barrier(0);
+      t0a = now();
       stage_next();  // K-tile NB - 1 phases ahead, into the buffer both groups finished reading one interval ago
       __builtin_amdgcn_sched_barrier(0);
+      t0b = now();
+      }
       // this wave's pieces of the NEXT K-tile have landed: its batch is followed by NB - 2 younger batches (OPS0 / OPS1
       // DMAs each) and, for the NB - 2 phases behind an epilogue, by that epilogue's NST stores (the batch of K-tile
       // kt + 1 was issued NB - 2 intervals before this one; the stores at kt = 0, in front of that interval's batch)
@@ -618,7 +760,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: the fragment reads have returned
         t1 = now();
       }
-      if (NHI == 0 || !hi) {
+      const bool behind_epi = pending && kt < NB - 2;
+      if constexpr (TUNE != 0) {
+        if ((TUNE & 1) && grp == 0) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); the DMA wait follows the MFMAs
+        else wait_batches(behind_epi, true);
+      } else if (NHI == 0 || !hi) {
         if (pending && kt < NB - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSLO * (NB - 2) + NST) & 0xF0FF);  // + lgkmcnt(0)
         else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSLO * (NB - 2)) & 0xF0FF);
       } else {
@@ -626,6 +772,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSHI * (NB - 2)) & 0xF0FF);
       }
       if constexpr (PROBE & 8) t2 = now();
+      if constexpr (TUNE & 2) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       const long long t3 = now();
@@ -653,10 +800,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
       }
       __builtin_amdgcn_sched_barrier(0);
       const long long t4 = now();
+      if constexpr (TUNE & 1) {
+        // group 0's pieces of K-tile kt + 1: first read (by group 0 itself) behind the barrier below, which group 1
+        // passes only after its own wait for the same K-tile at the end of its LOAD interval
+        if (grp == 0) wait_batches(behind_epi, false);
+      }
       __builtin_amdgcn_s_barrier();
       if constexpr (PROBE & 8) {
         const long long t5 = now();
         pt[0] += t1 - t0; pt[1] += t2 - t1; pt[2] += t3 - t2; pt[3] += t4 - t3; pt[4] += t5 - t4; pt[5] += 1;
+        pt[6] += t0a - t0e; pt[7] += t0b - t0a;   // fragment-read issue; DMA issue (both inside pt[0], as is the epilogue)
       }
       rbuf = rbuf + 1 == NB ? 0 : rbuf + 1;
     }
@@ -667,9 +820,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's last interval
   if constexpr (PROBE & 8) {
     if (lane == 0 && bias) {
-      long long* o = (long long*)bias + ((size_t)blockIdx.x * 8 + wave) * 6;
+      long long* o = (long long*)bias + ((size_t)blockIdx.x * 8 + wave) * 8;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) o[i] = pt[i];
+      for (int i = 0; i < 8; ++i) o[i] = pt[i];
     }
   }
   epilogue(pm0, pn0);
@@ -740,6 +893,8 @@ static std::atomic<int> g_s256_probe{0};
 void set_s256_probe(int v) { g_s256_probe.store(v); }
 static std::atomic<int> g_s256_rows{0};   // 0 = automatic, 256 / 288 / 320 = forced tile height (A/B hook)
 void set_s256_rows(int v) { g_s256_rows.store(v); }
+static std::atomic<int> g_s256_tune{0};   // TUNE of gemm_bf16_s256 (A/B hook; the instantiated values only)
+void set_s256_tune(int v) { g_s256_tune.store(v); }
 
 static int cu_count(int* cus) {   // CUs of the current device (cached per device: this sits on every launch path)
   static std::atomic<int> cache[DARK_MAX_DEVICES] = {};
@@ -785,16 +940,17 @@ double s256_best_cost(int epi, int M, int N, int* cus_out) {
 }
 
 // one launch of gemm_bf16_s256<E, PB, MI_> with everything the kernel derives from the tile height
-#define DARK_S256_LAUNCH(E, PB, MI_, BIAS_PTR, MDEV, C2, RANGE)                                                       \
+#define DARK_S256_LAUNCH_T(E, PB, MI_, TU, BIAS_PTR, MDEV, C2, RANGE)                                                 \
   {                                                                                                                   \
     const int tilesM = cdiv(M, 32 * MI_), ntiles = tilesM * tilesN, grid = min(ntiles, cus);                          \
     const int smem = s_smem(E, MI_) + (E == EPI_BIAS ? tilesN * 256 * 4 : 0);                                         \
     static SmemOptIn optin;                                                                                           \
-    DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<E, PB, MI_>, smem, st));                                        \
-    hipLaunchKernelGGL((gemm_bf16_s256<E, PB, MI_>), dim3(grid), dim3(512), smem, st, (const bf16_t*)A,               \
+    DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<E, PB, MI_, TU>, smem, st));                                    \
+    hipLaunchKernelGGL((gemm_bf16_s256<E, PB, MI_, TU>), dim3(grid), dim3(512), smem, st, (const bf16_t*)A,           \
                        (const bf16_t*)W, BIAS_PTR, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes, o_bytes, \
                        MDEV, C2, RANGE);                                                                              \
   }
+#define DARK_S256_LAUNCH(E, PB, MI_, BIAS_PTR, MDEV, C2, RANGE) DARK_S256_LAUNCH_T(E, PB, MI_, 0, BIAS_PTR, MDEV, C2, RANGE)
 #define DARK_S256_EITHER(E, MDEV, C2, RANGE)                                \
   if (mi == 10) DARK_S256_LAUNCH(E, 0, 10, bias, MDEV, C2, RANGE)           \
   else if (mi == 9) DARK_S256_LAUNCH(E, 0, 9, bias, MDEV, C2, RANGE)        \
@@ -811,6 +967,7 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   const unsigned o_bytes = (unsigned)((int64_t)M * ldo * es);
   const int mi = s256_pick_mi(epi, M, tilesN, cus);
   const int probe = epi == EPI_SWIGLU ? g_s256_probe.load() : 0;   // timing probes: gate/up flavour, 256-row tile
+  const int tune = g_s256_tune.load(std::memory_order_relaxed);
   const int* no_mdev = nullptr;
   if (probe == 1) DARK_S256_LAUNCH(EPI_SWIGLU, 1, 8, bias, no_mdev, 0.f, 0.f)
   else if (probe == 2) DARK_S256_LAUNCH(EPI_SWIGLU, 2, 8, bias, no_mdev, 0.f, 0.f)
@@ -820,7 +977,36 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   else if (probe == 8) DARK_S256_LAUNCH(EPI_SWIGLU, 8, 8, bias, no_mdev, 0.f, 0.f)
   else if (probe == 128) DARK_S256_LAUNCH(EPI_SWIGLU, 128, 8, bias, no_mdev, 0.f, 0.f)
   else if (probe == 132) DARK_S256_LAUNCH(EPI_SWIGLU, 132, 8, bias, no_mdev, 0.f, 0.f)
+  else if (probe == 16) DARK_S256_LAUNCH(EPI_SWIGLU, 16, 8, bias, no_mdev, 0.f, 0.f)
+  else if (probe == 144) DARK_S256_LAUNCH(EPI_SWIGLU, 144, 8, bias, no_mdev, 0.f, 0.f)
+  else if (probe == 148) DARK_S256_LAUNCH(EPI_SWIGLU, 148, 8, bias, no_mdev, 0.f, 0.f)
   else if (probe == 9) DARK_S256_LAUNCH(EPI_SWIGLU, 8, 10, bias, no_mdev, 0.f, 0.f)   // (per-phase sums of the 320-row tile)
+  else if (probe == 24 + 64) DARK_S256_LAUNCH_T(EPI_SWIGLU, 8, 10, 1, bias, no_mdev, 0.f, 0.f)   // (per-phase sums, TUNE 1)
+  else if (probe == 24 + 65) DARK_S256_LAUNCH_T(EPI_SWIGLU, 8, 10, 5, bias, no_mdev, 0.f, 0.f)   // (per-phase sums, TUNE 5)
+  else if (probe == 24 + 66) DARK_S256_LAUNCH_T(EPI_SWIGLU, 8, 10, 8, bias, no_mdev, 0.f, 0.f)   // (per-phase sums, TUNE 8)
+  else if (tune != 0 && mi >= 9 && (epi == EPI_SWIGLU || epi == EPI_BIAS || epi == EPI_RESID_H)) {
+#define DARK_S256_TUNED(TU)                                                                     \
+    if (epi == EPI_SWIGLU) {                                                                    \
+      if (mi == 10) DARK_S256_LAUNCH_T(EPI_SWIGLU, 0, 10, TU, bias, no_mdev, 0.f, 0.f)          \
+      else DARK_S256_LAUNCH_T(EPI_SWIGLU, 0, 9, TU, bias, no_mdev, 0.f, 0.f)                    \
+    } else if (epi == EPI_BIAS) {                                                               \
+      if (mi == 10) DARK_S256_LAUNCH_T(EPI_BIAS, 0, 10, TU, bias, no_mdev, 0.f, 0.f)            \
+      else DARK_S256_LAUNCH_T(EPI_BIAS, 0, 9, TU, bias, no_mdev, 0.f, 0.f)                      \
+    } else {                                                                                    \
+      if (mi == 10) DARK_S256_LAUNCH_T(EPI_RESID_H, 0, 10, TU, bias, no_mdev, 0.f, 0.f)         \
+      else DARK_S256_LAUNCH_T(EPI_RESID_H, 0, 9, TU, bias, no_mdev, 0.f, 0.f)                   \
+    }
+    if (tune == 1) { DARK_S256_TUNED(1) }
+    else if (tune == 2) { DARK_S256_TUNED(2) }
+    else if (tune == 5) { DARK_S256_TUNED(5) }
+    else if (tune == 4) { DARK_S256_TUNED(4) }
+    else if (tune == 8) { DARK_S256_TUNED(8) }
+    else if (tune == 9) { DARK_S256_TUNED(9) }
+    else if (tune == 5 + (5 << 4)) { DARK_S256_TUNED(85) }
+    else if (tune == 5 + (7 << 4)) { DARK_S256_TUNED(117) }
+    else { set_error("gemm_s256: TUNE %d is not instantiated", tune); return DARK_ERR_ARG; }
+#undef DARK_S256_TUNED
+  }
   else if (epi == EPI_SWIGLU) { DARK_S256_EITHER(EPI_SWIGLU, no_mdev, 0.f, 0.f) }
   else if (epi == EPI_BIAS) { DARK_S256_EITHER(EPI_BIAS, no_mdev, 0.f, 0.f) }
   else if (epi == EPI_RESID_H) { DARK_S256_EITHER(EPI_RESID_H, no_mdev, 0.f, 0.f) }
@@ -873,5 +1059,6 @@ int launch_gemm_s256_devrows(const void* A, const void* W, void* out, int M, int
 }
 #undef DARK_S256_EITHER
 #undef DARK_S256_LAUNCH
+#undef DARK_S256_LAUNCH_T
 
 }  // namespace dark

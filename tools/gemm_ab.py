@@ -97,6 +97,18 @@ def main():
                 torch.cuda.synchronize()
                 if r:
                     times[v].append(e0.elapsed_time(e1) / args.iters)
+        # ---- the variants' outputs at the timed size, bit for bit against the first one
+        base_o = (torch.randn(M, ldo, device=dev) * 0.1).to(o.dtype)
+        first = None
+        for v in variants:
+            _hip.check(lib.dark_dbg_set_gemm_variant(v))
+            oo = base_o.clone()
+            _hip.check(lib.dark_dbg_gemm(1, epi, _hip.ptr(A), _hip.ptr(Wt), bptr, _hip.ptr(oo), M, N, K, ldo, st))
+            torch.cuda.synchronize()
+            if first is None:
+                first = oo
+            elif v != 3 and not (16 <= v < 1000):
+                print(f"{name:16s} M={M}: variant {v} bit-identical to variant {variants[0]}: {torch.equal(first, oo)}", flush=True)
         for v in variants:
             ts = sorted(times[v])
             med = ts[len(ts) // 2]
