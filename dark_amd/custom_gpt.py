@@ -12,9 +12,12 @@ Compute: ``dark_gpt2_forward_hidden`` / ``dark_gpt2_lm_head_rows`` (``csrc/gpt2.
 kernels of the Dream path.  No CPU or PyTorch fallback.
 
 Attention semantics: the reference sets every block's ``attn.bias`` buffer to ones "to allow bidirectional attention"
-(:34-36).  ``attn_causal=False`` (default) is that intent; ``attn_causal=True`` is what transformers computes when its
-attention implementation ignores the buffer (the sdpa path of the pinned 4.50.2, and 5.x).  Both are pinned against
-transformers' own GPT-2 (``tests/golden/make_goldens_gpt2.py``).
+(:34-36), but the pinned transformers 4.50.2 selects its sdpa attention, which never reads that buffer and builds the
+causal mask itself (5.x has no such buffer at all): what the reference COMPUTES, trains and evaluates with is causal
+attention.  ``attn_causal=True`` (the default) is therefore the reference's behaviour -- the goldens of the reference's
+own class are reproduced with it -- and ``attn_causal=False`` is the explicit opt-in for the bidirectional attention
+the comment states as the intent.  Both are pinned against transformers' own GPT-2
+(``tests/golden/make_goldens_gpt2.py``).
 """
 from __future__ import annotations
 
@@ -41,7 +44,7 @@ class GPT2DiffusionConfig:
 
     def __init__(self, vocab_size=50257, n_positions=1024, n_embd=768, n_layer=12, n_head=12, n_inner=None,
                  activation_function="gelu_new", layer_norm_epsilon=1e-5, initializer_range=0.02,
-                 bos_token_id=50256, eos_token_id=50256, pad_token_id=None, attn_causal=False, **kwargs):
+                 bos_token_id=50256, eos_token_id=50256, pad_token_id=None, attn_causal=True, **kwargs):
         self.vocab_size, self.n_positions, self.n_embd = vocab_size, n_positions, n_embd
         self.n_layer, self.n_head, self.n_inner = n_layer, n_head, n_inner
         self.activation_function = activation_function
@@ -272,7 +275,7 @@ class DiffusionModel(DreamGenerationMixin, nn.Module):
         self.transformer = _Transformer(config, inner)
         self.lm_head = _Head(self.transformer.wte.weight)
         self.config.use_cache = False                                     # :39
-        self.attn_causal = bool(getattr(config, "attn_causal", False))
+        self.attn_causal = bool(getattr(config, "attn_causal", True))
         self.generation_config = self.generation_config_class.from_model_config(config)
         self._packed: Optional[PackedGpt2Weights] = None
         self._packed_key = None

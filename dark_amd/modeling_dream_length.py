@@ -439,7 +439,17 @@ class DreamModel_length(DreamGenerationMixin, nn.Module):
             raise OSError(f"{path} is not a local directory (hub downloads are not available)")
         cfg = config or DreamConfig.from_pretrained(path)
         model = cls(cfg)
-        files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+        index = os.path.join(path, "model.safetensors.index.json")
+        if os.path.exists(index):   # sharded by HF's writer: the shards its weight_map names, nothing else
+            with open(index) as f:
+                files = sorted(set(json.load(f)["weight_map"].values()))
+            absent = [f for f in files if not os.path.exists(os.path.join(path, f))]
+            if absent:
+                raise OSError(f"{index} names shards that are not in {path}: {absent}")
+        elif os.path.exists(os.path.join(path, "model.safetensors")):
+            files = ["model.safetensors"]
+        else:
+            files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
         if not files:
             raise OSError(f"no .safetensors file in {path}")
         sd: Dict[str, torch.Tensor] = {}
@@ -527,4 +537,6 @@ class DreamModel_length(DreamGenerationMixin, nn.Module):
         logits = st.head_all_rows().view(B, N, self.config.vocab_size)
         if num_logits_to_keep:
             logits = logits[:, -num_logits_to_keep:, :]
-        return MaskedLMOutput(logits=logits.clone())
+        # the reference's lm_head returns the model's dtype (modeling_dream_length.py:809: bf16 logits from a bf16 model,
+        # e.g. under the autocast of custom_grpo2.py:409-418); the head GEMM here accumulates and stores fp32
+        return MaskedLMOutput(logits=logits.to(self.dtype) if self.dtype == torch.bfloat16 else logits.clone())

@@ -12,6 +12,7 @@ SHAPE = dict(vocab_size=512, n_positions=64, n_embd=128, n_layer=2, n_head=2)
 def test_state_dict_names_and_tied_head():
     cfg = GPT2DiffusionConfig(**SHAPE)
     m = DiffusionModel(cfg)
+    assert cfg.attn_causal and m.attn_causal   # the default is what the reference computes
     names = {n for n, _ in synth.gpt2_state_dict_layout(cfg)} | {"lm_head.weight"}
     assert set(m.state_dict().keys()) == names
     for n, shape in synth.gpt2_state_dict_layout(cfg):

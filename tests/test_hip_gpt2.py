@@ -128,6 +128,24 @@ def test_forward_fp32_matches_transformers(gold, causal):
             assert float((got - want).abs().max()) < 5e-5 * max(1.0, float(want.abs().max()))
 
 
+def test_default_attention_is_what_the_reference_computes(gold):
+    """No `attn_causal` given: causal attention -- what the reference's class computes under its pinned transformers
+    (custom_gpt.py:34-36 fills a buffer the sdpa path never reads) and what its goldens were produced with."""
+    meta, g = gold
+    f = meta["forward"][0]
+    tag = f["tag"]
+    cfg = GPT2DiffusionConfig(**f["shape"], bos_token_id=BOS, eos_token_id=END, pad_token_id=END, mask_token_id=MASK)
+    assert cfg.attn_causal is True
+    m = DiffusionModel(cfg)
+    assert m.attn_causal is True
+    m.load_state_dict(synth.make_gpt2_weights(GPT2DiffusionConfig(**f["shape"]), seed=0, rich=True), strict=True)
+    m = m.to(DEV)
+    ids = torch.from_numpy(g[f"fwd_{tag}_ids"]).to(DEV)
+    got = m(ids).logits.cpu()
+    want = torch.from_numpy(g[f"fwd_{tag}_nomask_causal"])
+    assert float((got - want).abs().max()) < 5e-5 * max(1.0, float(want.abs().max()))
+
+
 def test_forward_bf16_close_to_fp32(gold):
     """bf16 (stated looser bound): logits within 3 % of the logit range of the fp32 goldens."""
     meta, g = gold
