@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-peaked-leg", action="store_true", help="skip the value_peaked_rows leg (A/B runs)")
     ap.add_argument("--materialise-noise", action="store_true",
                     help="fill the [M,V] categorical noise with torch instead of computing it in the sampler")
     ap.add_argument("--cpu-sample", type=int, default=48, help="sequences in the CPU-oracle sample")
@@ -105,6 +106,8 @@ def main():
     local_rank = 0 if args.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:   # (also under an external launcher, which does not set a per-rank thread count)
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 16) // world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     grouped = world > 1 or args.force_dist
@@ -142,10 +145,10 @@ def main():
     import warnings
     warnings.filterwarnings("ignore", message="Padding was detected")
 
-    def one_step(**over):
+    def one_step(mdl=None, **over):
         seqs = []
         for ids in (ids_abd, ids_ded):
-            seqs.append(model.diffusion_generate(ids, generation_config=gc, **dict(gen_kw, **over)))
+            seqs.append((mdl or model).diffusion_generate(ids, generation_config=gc, **dict(gen_kw, **over)))
         out = torch.cat(seqs, 0)
         if grouped:  # per-batch result gather (replaces all_gather_object of mdm_unify.py:436-438)
             out = dispatch.gather_rows(out, out.shape[0] * world)
@@ -182,10 +185,36 @@ def main():
     fence()
     dt_skip = time.perf_counter() - t1
 
+    # third figure: the same workload on weights whose rows are as peaked as a trained checkpoint's (final-norm weight
+    # x 6, as tools/head_fused_bench.py --peaks 6 makes them), so that the fused head + sampler (dark_head_sample_rows:
+    # no [M, V] logits) stays on; on the random-init weights of the headline the library's own statistics switch it off
+    # (most rows are flat and need their logits anyway).  Every step runs its forward, as in the headline.
+    dt_peaked, peaked_stats = None, None
+    if args.dtype == "bf16" and not args.no_peaked_leg:
+        w6 = dict(weights)
+        w6["model.norm.weight"] = weights["model.norm.weight"] * 6.0
+        model6 = DreamModel_length(cfg)
+        model6.residual_in_fp32 = bool(args.residual_fp32)
+        model6.load_state_dict(w6, strict=True)
+        model6 = model6.to(dev).to(tdt)
+        one_step(model6)
+        fence()
+        for st_ in model6._states.values():
+            st_.head_stats.zero_()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(model6)
+        fence()
+        dt_peaked = time.perf_counter() - t2
+        hs = sum(st_.head_stats.cpu().long() for st_ in model6._states.values())
+        peaked_stats = {"rows_sampled_by_fused_head": int(hs[0]), "rows_that_needed_logits": int(hs[1])}
+        del model6
+
     if grouped:
-        t = torch.tensor([dt, dt_skip], device="cpu" if args.rehearse else dev, dtype=torch.float64)
+        t = torch.tensor([dt, dt_skip, dt_peaked or 0.0], device="cpu" if args.rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt_skip = float(t[0]), float(t[1])
+        dt_peaked = float(t[2]) if dt_peaked is not None else None
     seq_per_s = args.batch * world * args.steps / dt
 
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
@@ -206,6 +235,10 @@ def main():
                    "residual_stream": "f32" if (args.residual_fp32 or args.dtype == "f32") else "bf16",
                    **({"collectives": "nccl (forced at world size 1)"} if args.force_dist and not args.rehearse else {})},
         "value_skip_noop_steps": round(args.batch * world * args.steps / dt_skip, 2),
+        **({"value_peaked_rows": round(args.batch * world * args.steps / dt_peaked, 2),
+            "peaked_rows": dict(peaked_stats, weights="random-init, final-norm weight x 6 (rows as peaked as a trained "
+                                                     "checkpoint's at T = 0.1); head + sampler fused, no [M, V] logits")}
+           if dt_peaked else {}),
         # SURVEY 8(d)'s algorithmic FLOPs (every row through every layer, head on masked rows) over the dense peak ...
         "forward_mfma_frac": round(alg_flops * args.steps * world / dt / 1e12 / (peak * world), 4),
         # ... and the FLOPs this build executes (last layer's o_proj / MLP on the masked rows only)
@@ -218,9 +251,13 @@ def main():
                      "frac": round(achieved / peak, 4),
                      # HBM-side bytes per launch from rocprofv3 PMC (FETCH_SIZE doubled per the gfx950 note, +
                      # WRITE_SIZE), separate passes, profiles/r02zzf_pmc.txt; valid for the default shape and kernel
-                     "traffic": 453.6e6 if (args.dtype == "bf16" and args.batch == 1024 and args.gemm_variant == 0) else None,
+                     # (rocprofv3 cannot run inside this process: the sidecar profiles/roofline_traffic.json holds the
+                     # per-launch figure of the PMC passes over THIS command on the build it names, written by
+                     # tools/profile_round.sh; null when it is absent or was taken for another shape / kernel)
+                     **roofline_traffic(args),
                      "algorithmic_bytes": 2.0 * (half * 46 * 768 + 6144 * 768 + half * 46 * 3072),
-                     "launches": n.value,
+                     "launches": n.value,   # bracketed launches (the hook brackets at most 8192 per read: all of a default run)
+                     "launches_cap": 8192,
                      "avg_launch_ms": round(ms.value / max(n.value, 1), 4)},
     }
 
@@ -230,6 +267,21 @@ def main():
         print(json.dumps(result), flush=True)
     if grouped:
         dist.destroy_process_group()
+
+
+def roofline_traffic(args):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE doubled per the gfx950
+    note of the microarchitecture guide + WRITE_SIZE, separate passes)."""
+    path = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    try:
+        with open(path) as f:
+            side = json.load(f)
+    except (OSError, ValueError):
+        return {"traffic": None, "traffic_source": None}
+    ok = (args.dtype == side.get("dtype") and args.batch == side.get("batch") and args.gemm_variant == 0
+          and not args.residual_fp32)
+    return {"traffic": float(side["traffic_bytes_per_launch"]) if ok else None,
+            "traffic_source": side.get("source") if ok else None}
 
 
 def spawn_ranks(args):
@@ -242,8 +294,12 @@ def spawn_ranks(args):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
+    # host threads per rank: the per-step sequencing is one Python thread; torch's intra-op pool must not oversubscribe
+    # the host when N ranks share it (the box sets OMP_NUM_THREADS for ONE process)
+    box_threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, os.cpu_count() or 16)
+    per_rank = str(max(1, box_threads // args.gpus))
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+        env = dict(os.environ, OMP_NUM_THREADS=per_rank, MKL_NUM_THREADS=per_rank, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,

@@ -13,7 +13,9 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdark_hip.so")
+# DARK_HIP_LIB: measurement tools point this at the probe build (libdark_hip_probes.so, `make -C dark_amd/csrc probes`);
+# it must export the same ABI -- load() checks every symbol either way.
+LIB_PATH = os.environ.get("DARK_HIP_LIB") or os.path.join(_HERE, "libdark_hip.so")
 
 DARK_OK, DARK_ERR_ARG, DARK_ERR_HIP, DARK_ERR_UNSUPPORTED = 0, 1, 2, 3
 DARK_F32, DARK_BF16 = 0, 1
@@ -198,16 +200,22 @@ _row_ws = {}   # device index -> uint8 tensor registered with dark_sampler_set_r
 def ensure_sampler_rows(M: int, V: int) -> None:
     """Vocabularies beyond DARK_SAMPLE_LDS_MAX_V (WN18RR: 41 066): the sampler keeps its rows in a device workspace
     that the caller registers, because no entry point allocates.  One buffer per device (the CURRENT device, which
-    the library requires to be the tensors' device), grown when a call needs more, shared by every model on it."""
+    the library requires to be the tensors' device), grown when a call needs more, shared by every model on it:
+    sampler calls with V > DARK_SAMPLE_LDS_MAX_V that OVERLAP on one GPU (two streams, two host threads) race on it --
+    the one-stream-at-a-time contract of include/dark_hip.h (dark_sampler_set_row_workspace)."""
     if V <= SAMPLE_LDS_MAX_V or M <= 0:
         return
     need = M * ((V + 3) & ~3) * 4
     dev = torch.cuda.current_device()
     buf = _row_ws.get(dev)
     if buf is None or buf.numel() < need:
+        if buf is not None:
+            # a sampler launch on ANOTHER stream may still read the old buffer: torch's allocator orders reuse on the
+            # allocation stream only, so wait for the device before the old buffer is dropped (growth is rare)
+            torch.cuda.synchronize(dev)
         buf = torch.empty(need, dtype=torch.uint8, device=torch.device("cuda", dev))
         check(_lib.dark_sampler_set_row_workspace(buf.data_ptr(), buf.numel()))
-        _row_ws[dev] = buf   # (the previous buffer returns to torch's allocator: reuse is ordered on the stream)
+        _row_ws[dev] = buf
 
 
 def _with_row_workspace(fn, m_at: int, v_at):

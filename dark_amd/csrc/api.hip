@@ -155,7 +155,7 @@ static int lm_head_rows(const dark_model_desc* m, const void* hidden, const int3
 // resolved per device with hipGetSymbolAddress and that pointer is what the kernels receive.
 constexpr size_t kNoAllocScratchBytes = DARK_NOALLOC_SCRATCH_BYTES;
 static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
-static void* g_scratch_ptr[DARK_MAX_DEVICES] = {};
+static std::atomic<void*> g_scratch_ptr[DARK_MAX_DEVICES] = {};
 static std::atomic<int> g_scratch_ready[DARK_MAX_DEVICES] = {};
 
 // Device address of `scratch` on the CURRENT device (resolved once per device, with that device current).
@@ -167,10 +167,10 @@ static int scratch_on_current_device(void** out) {
     void* p = nullptr;
     DARK_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
     DARK_CHECK_ARG(p != nullptr, "hipGetSymbolAddress returned a null scratch address on device %d", dev);
-    g_scratch_ptr[dev] = p;  // racing threads resolve the same address: benign
+    g_scratch_ptr[dev].store(p, std::memory_order_relaxed);  // (racing threads resolve the same address)
     g_scratch_ready[dev].store(1, std::memory_order_release);
   }
-  *out = g_scratch_ptr[dev];
+  *out = g_scratch_ptr[dev].load(std::memory_order_relaxed);
   return DARK_OK;
 }
 
@@ -378,6 +378,15 @@ int dark_lm_head_rows_noalloc(const dark_model_desc* m, const void* hidden, cons
                  "%zu (at most %zu rows); use dark_lm_head_rows with a workspace for larger batches",
                  M, m->d, m->dtype == DARK_BF16 ? "bf16" : "fp32", need, kNoAllocScratchBytes,
                  kNoAllocScratchBytes / ((size_t)m->d * esize(m->dtype)));
+  // the scratch array resolved below is the CURRENT device's copy: refuse a stream of another device before anything
+  // is enqueued on it (hipStreamGetDevice; the null stream belongs to the current device)
+  if (stream) {
+    int cur = 0;
+    hipDevice_t sdev = 0;
+    DARK_CHECK_HIP(hipGetDevice(&cur));
+    DARK_CHECK_HIP(hipStreamGetDevice((hipStream_t)stream, &sdev));
+    DARK_CHECK_ARG((int)sdev == cur, "lm_head_rows_noalloc: the stream belongs to device %d, the current device is %d", (int)sdev, cur);
+  }
   void* ws = nullptr;
   DARK_TRY(scratch_on_current_device(&ws));
   // from here on only `ws` (the resolved device pointer) is used, never the array's name

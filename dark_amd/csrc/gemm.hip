@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.h"
+#include <mutex>
 
 namespace dark {
 
@@ -630,15 +631,17 @@ static int launch_epi(int dtype, const void* A, const void* W, const float* bias
 // ---- optional HIP-event timing of one GEMM flavour (bench.py roofline leg) ----
 namespace {
 struct Prof {
-  int epi = -1;  // -1: off
+  std::atomic<int> epi{-1};  // -1: off
   int rows = 0;  // > 0: only launches with exactly this many rows
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   size_t used = 0;
   double flops = 0.0;
 } g_prof;
+std::mutex g_prof_mu;   // launches from several host threads may bracket themselves concurrently
 }  // namespace
 
 int prof_select(int epi, int rows) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof.epi = epi;
   g_prof.rows = rows;
   g_prof.used = 0;
@@ -647,6 +650,7 @@ int prof_select(int epi, int rows) {
 }
 
 int prof_read(double* total_ms, double* total_flops, int* launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   double ms = 0.0;
   for (size_t i = 0; i < g_prof.used; ++i) {
     DARK_CHECK_HIP(hipEventSynchronize(g_prof.ev[i].second));
@@ -667,6 +671,9 @@ static int launch_gemm_impl(int dtype, int epi, const void* A, const void* W, co
 
 int launch_gemm(int dtype, int epi, const void* A, const void* W, const float* bias, void* out, int M,
                 int N, int K, int64_t ldo, hipStream_t st) {
+  if (g_prof.epi < 0) return launch_gemm_impl(dtype, epi, A, W, bias, out, M, N, K, ldo, st);   // hook off: no lock
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  // (at most PROF_MAX_LAUNCHES launches are bracketed per read; later ones run unbracketed and are not in the average)
   if (g_prof.epi != epi || g_prof.used >= 8192 || (g_prof.rows > 0 && g_prof.rows != M)) return launch_gemm_impl(dtype, epi, A, W, bias, out, M, N, K, ldo, st);
   if (g_prof.used == g_prof.ev.size()) {
     hipEvent_t a, b;

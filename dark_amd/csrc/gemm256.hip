@@ -868,12 +868,15 @@ int launch_gemm_p256(int epi, const void* A, const void* W, const float* bias, v
     hipLaunchKernelGGL((gemm_bf16_p256<E>), dim3(grid), dim3(512), P_SMEM, st, (const bf16_t*)A, (const bf16_t*)W, \
                        bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes);                         \
   }
+#ifdef DARK_PROBES   // (timing-only instantiation with WRONG results: the probe build only, see the Makefile)
   if (epi == EPI_SWIGLU && g_p256_nodma.load()) {
     static SmemOptIn optin;
     DARK_TRY(optin.ensure((const void*)gemm_bf16_p256<EPI_SWIGLU, true>, P_SMEM, st));
     hipLaunchKernelGGL((gemm_bf16_p256<EPI_SWIGLU, true>), dim3(grid), dim3(512), P_SMEM, st, (const bf16_t*)A,
                        (const bf16_t*)W, bias, out, M, N, K, ldo, tilesM, tilesN, ntiles, a_bytes, w_bytes);
-  } else if (epi == EPI_SWIGLU) DARK_P256(EPI_SWIGLU)
+  } else
+#endif
+  if (epi == EPI_SWIGLU) DARK_P256(EPI_SWIGLU)
   else if (epi == EPI_BIAS) DARK_P256(EPI_BIAS)
   else DARK_P256(EPI_F32)
 #undef DARK_P256
@@ -969,6 +972,14 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   const int probe = epi == EPI_SWIGLU ? g_s256_probe.load() : 0;   // timing probes: gate/up flavour, 256-row tile
   const int tune = g_s256_tune.load(std::memory_order_relaxed);
   const int* no_mdev = nullptr;
+#ifndef DARK_PROBES
+  // the shipped library holds the product instantiations only; timing probes (some give WRONG results) and the TUNE
+  // A/B forms exist in the probe build (make probes -> libdark_hip_probes.so, loaded by tools/ when DARK_HIP_LIB names it)
+  if (probe != 0 || tune != 0) {
+    set_error("gemm_s256: probe %d / TUNE %d need the probe build of the library (make -C dark_amd/csrc probes)", probe, tune);
+    return DARK_ERR_UNSUPPORTED;
+  }
+#else
   if (probe == 1) DARK_S256_LAUNCH(EPI_SWIGLU, 1, 8, bias, no_mdev, 0.f, 0.f)
   else if (probe == 2) DARK_S256_LAUNCH(EPI_SWIGLU, 2, 8, bias, no_mdev, 0.f, 0.f)
   else if (probe == 3) DARK_S256_LAUNCH(EPI_SWIGLU, 3, 8, bias, no_mdev, 0.f, 0.f)
@@ -1007,7 +1018,9 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
     else { set_error("gemm_s256: TUNE %d is not instantiated", tune); return DARK_ERR_ARG; }
 #undef DARK_S256_TUNED
   }
-  else if (epi == EPI_SWIGLU) { DARK_S256_EITHER(EPI_SWIGLU, no_mdev, 0.f, 0.f) }
+  else
+#endif
+  if (epi == EPI_SWIGLU) { DARK_S256_EITHER(EPI_SWIGLU, no_mdev, 0.f, 0.f) }
   else if (epi == EPI_BIAS) { DARK_S256_EITHER(EPI_BIAS, no_mdev, 0.f, 0.f) }
   else if (epi == EPI_RESID_H) { DARK_S256_EITHER(EPI_RESID_H, no_mdev, 0.f, 0.f) }
   else { DARK_S256_EITHER(EPI_F32, no_mdev, 0.f, 0.f) }

@@ -1084,7 +1084,15 @@ int launch_sample_indexed(const float* logits, int64_t ldl, int M, int V, float 
     DARK_CHECK_LAUNCH();
     hipLaunchKernelGGL(sample_kernel, dim3(M), dim3(ST), smem, st, logits, ldl, V, temperature, top_p, top_k, conf_mode,
                        noise, ldn, pn, conf, x0, row_ids, n_dev, 1);
-    DARK_CHECK_LAUNCH();
+    {  // the first stage is already enqueued and has marked its unfinished rows with x0 = -1: say so if the second is refused
+      const hipError_t e2 = hipGetLastError();
+      if (e2 != hipSuccess) {
+        set_error("sample_rows: the second stage of the two-stage sampler could not be launched (%s): conf / x0 are "
+                  "UNDEFINED for this call (rows the first stage did not finish hold x0 = -1) and must not be committed",
+                  hipGetErrorString(e2));
+        return DARK_ERR_HIP;
+      }
+    }
     return DARK_OK;
   }
   hipLaunchKernelGGL(sample_kernel, dim3(M), dim3(ST), smem, st, logits, ldl, V, temperature, top_p, top_k,

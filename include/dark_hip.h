@@ -133,7 +133,10 @@ int dark_lm_head_rows(const dark_model_desc* m, const void* hidden, const int32_
  * call.  Every call on a GPU shares that GPU's array: the array is fully rewritten for the M rows of each call, so
  * nothing has to be cleared, but two calls that OVERLAP on one GPU (different streams or host threads) race on it.
  * dark_noalloc_init() resolves the array's device address for the CURRENT device (hipGetSymbolAddress); the entry
- * point does the same on its first call on a device, so init is only needed to keep that lookup out of a capture.
+ * point does the same on its first call on a device.  The first call of each kernel flavour on a device also loads
+ * its code object and sets its dynamic-LDS attribute (hipFuncSetAttribute): before HIP graph capture, call
+ * dark_noalloc_init() and make ONE warm-up call of this entry point with the shapes to be captured.  `stream` must
+ * belong to the current device (checked before anything is enqueued; DARK_ERR_ARG otherwise).
  * Results are bit-identical to dark_lm_head_rows. */
 #define DARK_NOALLOC_SCRATCH_BYTES (8u << 20)
 int dark_noalloc_init(void);
@@ -459,13 +462,20 @@ int dark_dbg_gemm_resid_norm(const void* A, const void* W, float* hidden, const 
 /* Which bf16 GEMM kernel dark_dbg_gemm and the forward use (A/B measurements and tests):
  *   0 = the library's choice per shape;
  *   1 = always the 128-row kernels of gemm.hip (and the unfused head);
- *   2 = the persistent 256 x 256 kernel wherever it supports the shape; 3 = timing probe of it (WRONG results);
+ *   2 = the persistent 256 x 256 kernel wherever it supports the shape;
  *   4 = its staggered two-group form (gemm_bf16_s256) wherever it supports the shape, automatic tile height;
  *   8 / 9 / 10 = the same with the tile height forced to 256 / 288 / 320 rows;
  *   5 = the library's choice + the row-panel kernel for the residual projections (fp32 residual stream only);
  *   6 / 7 / 11 = the library's choice without its one-round down_proj routing / without q/k/v on the persistent
  *   kernel / with o_proj there too (the in-loop A/Bs recorded in DESIGN.md);
- *   16 + p = timing probe p of gemm_bf16_s256 (WRONG results unless p = 8 or 9: per-phase cycle sums). */
+ * PROBE BUILD ONLY (libdark_hip_probes.so: `make -C dark_amd/csrc probes`, -DDARK_PROBES; the shipped libdark_hip.so
+ * holds no instantiation that gives wrong results and answers DARK_ERR_UNSUPPORTED at the launch):
+ *   3 = timing probe of variant 2 (WRONG results); 16 + p = timing probe p of gemm_bf16_s256 (WRONG results unless
+ *   p = 8, 9 or 88..90: per-phase cycle sums); 1000 + t = the library's choice with gemm_bf16_s256's TUNE = t (A/B forms
+ *   of the interval structure, results unchanged; the values instantiated in gemm256.hip).
+ * THREADING: this switch, dark_dbg_set_sampler_stages, dark_prof_select_gemm* and dark_sampler_set_row_workspace are
+ * process-global settings read by every later launch on every stream: set them from one host thread while no other
+ * thread is inside the library.  (dark_prof_* keep their event list behind a mutex; the others are single atomics.) */
 int dark_dbg_set_gemm_variant(int variant);
 /* A/B and test hook of the sampler: 0 = automatic (plain calls with the nucleus filter on, top-k off and V <= 26 624
  * run the two-stage form: sample_head_kernel with the row in registers, then sample_kernel for the rows it marked),

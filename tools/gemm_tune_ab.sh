@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of gemm_bf16_s256's TUNE variants (dark_dbg_set_gemm_variant(1000 + TUNE)) on the three shapes the kernel serves.
+# Needs the probe build (make -C dark_amd/csrc probes).
 # Usage (GPU box): bash tools/gemm_tune_ab.sh OUT.txt "0,1001,1004,1005"
+export DARK_HIP_LIB=${DARK_HIP_LIB:-dark_amd/libdark_hip_probes.so}
 out=${1:-gpurun_out/tune_ab.txt}; vars=${2:-0,1001,1004,1005}
 : > "$out"
 for shape in "gate/up swiglu" "qkv" "down resid bf16"; do

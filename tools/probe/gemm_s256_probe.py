@@ -3,7 +3,8 @@
 removed (timing-only builds of the 256-row tile, WRONG results; dark_dbg_set_gemm_variant(16 + p)): p bit 0 = no LDS-DMA
 issue in the steady state, bit 1 = no fragment reads after the first K-tile, bit 2 = no epilogue, bit 7 = no MFMAs; then
 the per-phase s_memtime sums of both tile heights (correct results).  One process, interleaved rounds.
-Usage (GPU box): python tools/probe/gemm_s256_probe.py [--iters 40] [--rounds 5]"""
+Needs the probe build of the library (make -C dark_amd/csrc probes).
+Usage (GPU box): DARK_HIP_LIB=dark_amd/libdark_hip_probes.so python tools/probe/gemm_s256_probe.py [--iters 40] [--rounds 5]"""
 import argparse
 import os
 import sys
