@@ -39,7 +39,7 @@ template <> struct AttnVec<bf16_t> {
   }
 };
 
-template <typename T, int HD, int NT, int NW>
+template <typename T, int HD, int NT, int NW, bool HOIST = false>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv, const float* __restrict__ cosT,
                                                    const float* __restrict__ sinT,
                                                    const int32_t* __restrict__ pos,
@@ -68,6 +68,73 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv
   const int64_t ld = 3 * (int64_t)dm;
   const T* base = qkv + (int64_t)b * N * ld + h * HD;
 
+  if constexpr (!kF32 && HOIST) {
+    // ---- bf16: every global load of the staging phase is issued before the first one is used (one round trip to
+    // memory per workgroup instead of one per loop iteration: the workgroup's life is mostly this wait).  Loads are
+    // UNCONDITIONAL on a clamped token index -- an EXEC-masked load leaves its registers undefined -- and the padding
+    // rows are zeroed when they are written.
+    constexpr int ITQK = 2 * NP * PC / NTH, ITV = NP * VC / NTH;
+    static_assert(ITQK * NTH == 2 * NP * PC && ITV * NTH == NP * VC, "staging items must divide over the threads");
+    raw_t r1[ITQK], r2[ITQK], rv[ITV];
+    float4 cs[ITQK][2], sn[ITQK][2];
+#pragma unroll
+    for (int u = 0; u < ITQK; ++u) {
+      const int it = tid + u * NTH;
+      const int which = it / (NP * PC);
+      const int rem = it - which * (NP * PC);
+      const int t = rem / PC, c = rem - t * PC;
+      const int tc = t < N ? t : N - 1;
+      int p = pos ? pos[b * N + tc] : tc;
+      p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+      const T* src = base + (int64_t)tc * ld + which * dm + c * VEC;
+      r1[u] = *(const raw_t*)src;
+      r2[u] = *(const raw_t*)(src + HALF);
+      const float* cp = cosT + (int64_t)p * HALF + c * VEC;
+      const float* sp = sinT + (int64_t)p * HALF + c * VEC;
+      cs[u][0] = *(const float4*)cp; cs[u][1] = *(const float4*)(cp + 4);
+      sn[u][0] = *(const float4*)sp; sn[u][1] = *(const float4*)(sp + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < ITV; ++u) {
+      const int it = tid + u * NTH;
+      const int t = it / VC, c = it - t * VC;
+      const int tc = t < N ? t : N - 1;
+      rv[u] = *(const raw_t*)(base + (int64_t)tc * ld + 2 * dm + c * VEC);
+    }
+#pragma unroll
+    for (int u = 0; u < ITQK; ++u) {
+      const int it = tid + u * NTH;
+      const int which = it / (NP * PC);
+      const int rem = it - which * (NP * PC);
+      const int t = rem / PC, c = rem - t * PC;
+      float x1[VEC], x2[VEC], o1[VEC], o2[VEC];
+      AttnVec<T>::unpack(r1[u], x1);
+      AttnVec<T>::unpack(r2[u], x2);
+      const float cc[8] = {cs[u][0].x, cs[u][0].y, cs[u][0].z, cs[u][0].w, cs[u][1].x, cs[u][1].y, cs[u][1].z, cs[u][1].w};
+      const float ss[8] = {sn[u][0].x, sn[u][0].y, sn[u][0].z, sn[u][0].w, sn[u][1].x, sn[u][1].y, sn[u][1].z, sn[u][1].w};
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        o1[e] = t < N ? x1[e] * cc[e] - x2[e] * ss[e] : 0.f;
+        o2[e] = t < N ? x2[e] * cc[e] + x1[e] * ss[e] : 0.f;
+      }
+      T* dst = (which ? Ks : Qs) + t * LD + c * VEC;
+      *(raw_t*)dst = AttnVec<T>::pack(o1);
+      *(raw_t*)(dst + HALF) = AttnVec<T>::pack(o2);
+    }
+#pragma unroll
+    for (int u = 0; u < ITV; ++u) {
+      const int it = tid + u * NTH;
+      const int t = it / VC, c = it - t * VC;
+      raw_t v = rv[u];
+      if (t >= N) {
+        float z[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) z[e] = 0.f;
+        v = AttnVec<T>::pack(z);
+      }
+      *(raw_t*)(Vs + t * LD + c * VEC) = v;
+    }
+  } else {
   // ---- stage Q, K with RoPE
   for (int it = tid; it < 2 * NP * PC; it += NTH) {
     const int which = it / (NP * PC);
@@ -111,6 +178,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv
     }
     *(raw_t*)(Vs + t * LD + c * VEC) = v;
   }
+  }
   for (int j = tid; j < NP; j += NTH) {
     const bool on = j < N && (!kmask || kmask[b * N + j] != 0);
     kbias[j] = on ? 0.f : -INFINITY;
@@ -144,6 +212,40 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv
     const int qi = it * 16 + li;
     const bool q_on = qi < N && (!kmask || kmask[b * N + qi] != 0);
     float mx = -INFINITY;
+    if constexpr (!kF32) {
+      // bf16: P is rounded to bf16 before P V, so the softmax runs on the hardware exp2 (scale * log2(e) folded into
+      // one fma with the key bias) and ONE reciprocal per query instead of a libm expf and an IEEE division per
+      // score -- at N = 128 the kernel was bound by exactly that arithmetic (~35 vector instructions a score)
+      const float c2 = scale * 1.44269504088896340736f;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = __builtin_fmaf(S[jt][r], c2, kbias[jt * 16 + 4 * g + r]);
+          if (causal && jt * 16 + 4 * g + r > qi) s = -INFINITY;
+          S[jt][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mz = (mx == -INFINITY) ? 0.f : mx;   // a fully masked row: exp2(-inf - 0) = 0 everywhere
+      float sum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(S[jt][r] - mz);
+          S[jt][r] = e;
+          sum += e;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = (q_on && sum > 0.f) ? 1.0f / sum : 0.f;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[jt][r] *= inv;
+    } else {
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -171,6 +273,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) S[jt][r] = live ? S[jt][r] / sum : 0.f;
+    }
 
     // ---- O = P V
     T* orow = out + ((int64_t)b * N) * dm + h * HD;
@@ -232,19 +335,24 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const T* __restrict__ qkv
   }
 }
 
-template <typename T, int HD, int NT, int NW>
+template <typename T, int HD, int NT, int NW, bool HOIST = false>
 static int launch_attn_t(const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                          const uint8_t* kmask, void* out, int B, int N, int H, int max_pos, hipStream_t st, int causal) {
   constexpr int VEC = AttnVec<T>::VEC;
   constexpr int smem = 3 * NT * 16 * (HD + VEC) * (int)sizeof(T) + NT * 16 * 4;
   static SmemOptIn optin;
-  DARK_TRY(optin.ensure((const void*)attn_kernel<T, HD, NT, NW>, smem, st));
+  DARK_TRY(optin.ensure((const void*)attn_kernel<T, HD, NT, NW, HOIST>, smem, st));
   const float scale = 1.0f / sqrtf((float)HD);
-  hipLaunchKernelGGL((attn_kernel<T, HD, NT, NW>), dim3(B * H), dim3(NW * 64), smem, st, (const T*)qkv, cosT, sinT, pos,
+  hipLaunchKernelGGL((attn_kernel<T, HD, NT, NW, HOIST>), dim3(B * H), dim3(NW * 64), smem, st, (const T*)qkv, cosT, sinT, pos,
                      kmask, (T*)out, N, H, max_pos, scale, causal);
   DARK_CHECK_LAUNCH();
   return DARK_OK;
 }
+
+// A/B hook (dark_dbg_set_gemm_variant(12)): 1 = the N <= 128 instance without the hoisted staging loads
+static std::atomic<int> g_attn_variant{0};
+void set_attn_variant(int v) { g_attn_variant.store(v); }
+static int attn_variant() { return g_attn_variant.load(std::memory_order_relaxed); }
 
 int launch_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                      const uint8_t* kmask, void* out, int B, int N, int H, int HD, int max_pos,
@@ -259,7 +367,8 @@ int launch_attention(int dtype, const void* qkv, const float* cosT, const float*
 #define DARK_ATTN(T, HDv)                                                                                        \
   if (N <= 48) return launch_attn_t<T, HDv, 3, 3>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0);        \
   if (N <= 64) return launch_attn_t<T, HDv, 4, 4>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0);        \
-  return launch_attn_t<T, HDv, 8, 8>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0)
+  if (attn_variant() == 1) return launch_attn_t<T, HDv, 8, 8, false>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0); \
+  return launch_attn_t<T, HDv, 8, 8, true>(qkv, cosT, sinT, pos, kmask, out, B, N, H, max_pos, st, causal ? 1 : 0)
   if (dtype == DARK_BF16) {
     if (HD == 96) { DARK_ATTN(bf16_t, 96); } else { DARK_ATTN(bf16_t, 64); }
   } else {

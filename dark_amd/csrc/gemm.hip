@@ -703,7 +703,9 @@ double s256_best_cost(int epi, int M, int N, int* cus_out);
 // its tile height forced to 256 / 288 / 320 rows (A/B of the instantiations; other values leave the choice automatic)
 // 1000 + t = the automatic choice with gemm_bf16_s256's TUNE = t wherever that kernel runs (results unchanged)
 void set_s256_tune(int v);
+void set_attn_variant(int v);   // (attn.hip; 12 = the library's GEMM choice + the attention kernel's A/B form)
 void set_gemm_variant(int v) {
+  set_attn_variant(v == 12 ? 1 : 0);
   const bool tuned = v >= 1000;
   set_s256_tune(tuned ? v - 1000 : 0);
   if (tuned) v = 0;
@@ -745,7 +747,9 @@ static int pick_kernel(int dtype, int epi, int M, int N, int K, int64_t ldo, con
     int cus = 256;
     const double c256 = s256_best_cost(epi, M, N, &cus);
     const double c128 = (double)cdiv(cdiv(M, 128) * cdiv(N, 192), 2 * cus) * 192.0;   // two workgroups per CU
-    if (c256 * 1.1 < c128) return 4;
+    // (K >= 1536: at equal row-rounds the persistent kernel's longer main loop wins -- M = 131072, BASELINE config 4:
+    // 561 vs 588 us, profiles/r03o_gemm_ab_config4_rows.txt -- so no margin there)
+    if (epi == EPI_RESID_H && K >= 1536 ? c256 <= c128 : c256 * 1.1 < c128) return 4;
   }
   return 0;
 }

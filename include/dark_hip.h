@@ -468,6 +468,8 @@ int dark_dbg_gemm_resid_norm(const void* A, const void* W, float* hidden, const 
  *   5 = the library's choice + the row-panel kernel for the residual projections (fp32 residual stream only);
  *   6 / 7 / 11 = the library's choice without its one-round down_proj routing / without q/k/v on the persistent
  *   kernel / with o_proj there too (the in-loop A/Bs recorded in DESIGN.md);
+ *   12 = the library's GEMM choice with the N <= 128 attention instance's staging loads issued per loop iteration
+ *   instead of all up front (the round-2 form; results equal up to the contraction of one multiply-add in the rotation);
  * PROBE BUILD ONLY (libdark_hip_probes.so: `make -C dark_amd/csrc probes`, -DDARK_PROBES; the shipped libdark_hip.so
  * holds no instantiation that gives wrong results and answers DARK_ERR_UNSUPPORTED at the launch):
  *   3 = timing probe of variant 2 (WRONG results); 16 + p = timing probe p of gemm_bf16_s256 (WRONG results unless
