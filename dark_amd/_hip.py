@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("DARK_HIP_LIB") or os.path.join(_HERE, "libdark_hip.so
 DARK_OK, DARK_ERR_ARG, DARK_ERR_HIP, DARK_ERR_UNSUPPORTED = 0, 1, 2, 3
 DARK_F32, DARK_BF16 = 0, 1
 CONF_PROB, CONF_MARGIN, CONF_NEG_ENTROPY = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 SHARD_PART_BYTES = 280
 SAMPLE_LDS_MAX_V = 32768   # DARK_SAMPLE_LDS_MAX_V: larger vocabularies sample from a registered row workspace
 
@@ -146,6 +146,8 @@ SIGNATURES = {
     "dark_dbg_gemm_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                      C.c_void_p]),
     "dark_dbg_gemm_resid_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_float, C.c_void_p]),
+    "dark_dbg_gemm_resid_norm_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            C.c_float, C.c_void_p]),
     "dark_dbg_rmsnorm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_int, C.c_float, C.c_void_p]),

@@ -65,6 +65,11 @@ static int resid_gemm_norm(const dark_model_desc* m, const void* A, const void* 
   if (m->dtype == DARK_BF16 && m->resid_dtype == DARK_F32 && gemm_variant() == 5 &&
       rowpanel_supports(M, d, K, A, W, hidden, ln, ln ? xn : nullptr))
     return launch_gemm_resid_norm(A, W, (float*)hidden, ln, ln ? xn : nullptr, M, K, m->rms_eps, st);
+  // bf16 stream (round 3): the row-panel kernel gives the same bits as the two launches below (hidden AND xn), so it
+  // can be chosen per call: variant 5 = for both residual projections, 13 = for o_proj only (K = d)
+  if (m->dtype == DARK_BF16 && m->resid_dtype == DARK_BF16 && (gemm_variant() == 5 || (gemm_variant() == 13 && K == d)) &&
+      rowpanel_supports(M, d, K, A, W, hidden, ln, ln ? xn : nullptr))
+    return launch_gemm_resid_norm_h(A, W, hidden, ln, ln ? xn : nullptr, M, K, m->rms_eps, st);
   const int epi = m->resid_dtype == DARK_BF16 ? EPI_RESID_H : EPI_RESID;
   DARK_TRY(launch_gemm(m->dtype, epi, A, W, nullptr, hidden, M, d, K, d, st));
   if (ln) DARK_TRY(launch_rmsnorm(m->dtype, m->resid_dtype, hidden, ln, xn, nullptr, M, M, d, m->rms_eps, st));
@@ -522,7 +527,7 @@ int dark_prof_read(double* total_ms, double* total_flops, int* launches) {
 }
 
 int dark_dbg_set_gemm_variant(int variant) {
-  DARK_CHECK_ARG((variant >= 0 && variant <= 12) || (variant >= 16 && variant <= 16 + 255) || (variant >= 1000 && variant < 1128),
+  DARK_CHECK_ARG((variant >= 0 && variant <= 13) || (variant >= 16 && variant <= 16 + 255) || (variant >= 1000 && variant < 1128),
                  "set_gemm_variant: %d", variant);
   set_gemm_variant(variant);
   return DARK_OK;
@@ -542,6 +547,10 @@ int dark_dbg_gemm_head(const void* A, const void* W, void* records, int M, int N
 int dark_dbg_gemm_resid_norm(const void* A, const void* W, float* hidden, const float* ln_w, void* xn, int M, int K,
                              float eps, void* stream) {
   return launch_gemm_resid_norm(A, W, hidden, ln_w, xn, M, K, eps, (hipStream_t)stream);
+}
+int dark_dbg_gemm_resid_norm_h(const void* A, const void* W, void* hidden, const float* ln_w, void* xn, int M, int K,
+                               float eps, void* stream) {
+  return launch_gemm_resid_norm_h(A, W, hidden, ln_w, xn, M, K, eps, (hipStream_t)stream);
 }
 int dark_dbg_attention(int dtype, const void* qkv, const float* cosT, const float* sinT, const int32_t* pos,
                        const uint8_t* key_mask, void* out, int B, int N, int H, int HD, int max_pos, void* stream) {

@@ -202,6 +202,8 @@ bool rowpanel_supports(int M, int N, int K, const void* A, const void* W, const 
                        const void* xn);
 int launch_gemm_resid_norm(const void* A, const void* W, float* hidden, const float* ln_w, void* xn, int M, int K,
                            float eps, hipStream_t st);
+int launch_gemm_resid_norm_h(const void* A, const void* W, void* hidden, const float* ln_w, void* xn, int M, int K,
+                             float eps, hipStream_t st);   // the same on a bf16 residual stream
 
 int prof_select(int epi, int rows = 0);
 int prof_read(double* total_ms, double* total_flops, int* launches);

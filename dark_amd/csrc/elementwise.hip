@@ -165,6 +165,8 @@ __global__ __launch_bounds__(256) void rmsnorm_h16_kernel(const bf16_t* __restri
     src = src < 0 ? 0 : (src >= n_src ? n_src - 1 : src);
   }
   const bf16_t* xr = x + src * d;
+  // Summation order (part of the contract with gemm_rowpanel.hip, which rebuilds it to give the same bits): per 8-element
+  // piece an fma chain from zero; this lane's pieces added in order; then the butterfly below.
   bf16x8 v[4];
   float ss = 0.f;
 #pragma unroll
@@ -172,8 +174,10 @@ __global__ __launch_bounds__(256) void rmsnorm_h16_kernel(const bf16_t* __restri
     const int c = l * 8 + p * 256;
     if (c < d) {
       v[p] = *(const bf16x8*)(xr + c);
+      float q = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ss += (float)v[p][e] * (float)v[p][e];
+      for (int e = 0; e < 8; ++e) q = __builtin_fmaf((float)v[p][e], (float)v[p][e], q);
+      ss = p == 0 ? q : ss + q;
     }
   }
 #pragma unroll

@@ -728,7 +728,7 @@ static int pick_kernel(int dtype, int epi, int M, int N, int K, int64_t ldo, con
   // 6 / 7 / 11 = A/B of the automatic choice itself: 6 = without the one-round down_proj routing below, 7 = without
   // q/k/v on the 288-row persistent kernel, 11 = with o_proj there too
   const bool no_resid_s256 = v == 6, qkv_s256 = v != 7, oproj_s256 = v == 11;
-  if (v == 5 || v == 6 || v == 7 || v == 11) v = 0;  // 5 = automatic GEMM choice + the row-panel kernel for o_proj / down_proj (api.hip)
+  if (v == 5 || v == 6 || v == 7 || v == 11 || v == 12 || v == 13) v = 0;  // 5 / 13 = automatic GEMM choice + the row-panel kernel for o_proj + down_proj / o_proj only (api.hip); 12 = attention A/B
   if (v == 1) return 0;
   const bool p_ok = p256_supports(epi, M, N, K, ldo, out, bias), s_ok = s256_supports(epi, M, N, K, ldo, out, bias);
   if (v == 2) return p_ok ? 2 : 0;

@@ -25,6 +25,14 @@
 // four lanes of a row are combined by two xor-shuffles, the 8 wave partials are added in order 0..7.  The residual
 // stream is bit-identical to the unfused kernels'; xn differs from rmsnorm_kernel's by the rounding of a differently
 // associated fp32 sum (at most 1 bf16 ulp on a few elements in 10^4).
+//
+// HB = true (round 3): the residual stream is bf16 (the model dtype).  The epilogue brings two
+// adjacent 16-column tiles into 8 consecutive columns a lane (one permlane16_swap per register, as EPI_RESID_H of
+// gemm256.hip), adds the old bf16 values in fp32 and rounds once -- the same bits as the unfused residual GEMM -- and
+// normalises the ROUNDED values, which is what the separate norm kernel would read back.  The sum of squares follows
+// rmsnorm_h16_kernel's order exactly (elementwise.hip: per 8-column piece an fma chain from zero, the pieces l, l + 32,
+// l + 64 of virtual lane l added in that order, then the 16 / 8 / 4 / 2 / 1 butterfly over the 32 lanes), so xn is
+// bit-identical to the two-launch form too and the two can be mixed per shape.
 #include "common.h"
 
 namespace dark {
@@ -53,9 +61,9 @@ __device__ __forceinline__ uint32_t pk2(float lo, float hi) {
 template <int I> struct IC { static constexpr int value = I; };
 }  // namespace
 
-template <bool NORM>
+template <bool NORM, bool HB = false>
 __global__ __launch_bounds__(512) void gemm_bf16_rowpanel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
-                                                          float* __restrict__ hidden, const float* __restrict__ ln_w,
+                                                          void* __restrict__ hidden, const float* __restrict__ ln_w,
                                                           bf16_t* __restrict__ xn, int M, int K, float eps,
                                                           unsigned a_bytes, unsigned w_bytes, unsigned h_bytes,
                                                           unsigned x_bytes) {
@@ -169,6 +177,109 @@ __global__ __launch_bounds__(512) void gemm_bf16_rowpanel(const bf16_t* __restri
   }
 
   // ================= epilogue =================
+  if constexpr (HB) {
+    // ---- bf16 residual stream: lane = row (lane & 15) of each 16-row tile, 8 consecutive columns of each tile pair
+    const int hcol = (fq & 1) ? 16 + 4 * (fq - 1) : 4 * fq;
+    const int hp = ((fq & 1) << 1) | (fq >> 1);            // hcol / 8
+    u32x4_t hb[6][3];                                      // the new residual values, packed bf16 (kept for the norm)
+    float sp[6][3];                                        // per piece: sum of squares of the rounded values
+    u32x4_t old[2][3];
+    auto load_old = [&](u32x4_t (&dst)[3], int i) {
+      const int m = m0 + 16 * i + frow;
+#pragma unroll
+      for (int np = 0; np < 3; ++np)
+        dst[np] = __builtin_amdgcn_raw_buffer_load_b128(rh, m < M ? (unsigned)(m * R_N + wave * 96 + np * 32 + hcol) * 2u : OOB, 0, 0);
+    };
+    load_old(old[0], 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int m = m0 + 16 * i + frow;
+      if (i + 1 < 6) load_old(old[(i + 1) & 1], i + 1);
+#pragma unroll
+      for (int np = 0; np < 3; ++np) {
+        const f32x4 a = acc[2 * np][i], b = acc[2 * np + 1][i];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[e]), __float_as_uint(b[e]), false, false);
+          v[e] = __uint_as_float(sw[0]);
+          v[4 + e] = __uint_as_float(sw[1]);
+        }
+        const u32x4_t o = old[i & 1][np];
+        u32x4_t r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          r[j] = pk2(v[2 * j] + __uint_as_float(o[j] << 16), v[2 * j + 1] + __uint_as_float(o[j] & 0xffff0000u));
+        hb[i][np] = r;
+        __builtin_amdgcn_raw_buffer_store_b128(r, rh, m < M ? (unsigned)(m * R_N + wave * 96 + np * 32 + hcol) * 2u : OOB, 0, 0);
+        if constexpr (NORM) {
+          float q = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(r[j] << 16), hi = __uint_as_float(r[j] & 0xffff0000u);
+            q = __builtin_fmaf(lo, lo, q);
+            q = __builtin_fmaf(hi, hi, q);
+          }
+          sp[i][np] = q;
+        }
+      }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's last interval
+    if constexpr (NORM) {
+      __syncthreads();   // every wave is out of the main loop: the K-tile ring is dead and holds the piece sums now
+      float* ps = (float*)smem;                    // [96 rows][96 pieces of 8 columns]
+      float* tot = (float*)(smem + R_RED);         // [96 rows]
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int np = 0; np < 3; ++np) ps[(16 * i + frow) * 96 + 12 * wave + 4 * np + hp] = sp[i][np];
+      __syncthreads();
+      if (tid < 4 * R_BM) {
+        // four threads a row rebuild rmsnorm_h16_kernel's sum: thread qd holds virtual lanes 8 qd .. 8 qd + 7
+        const int row = tid >> 2, qd = tid & 3;
+        float part[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int L = 8 * qd + e;
+          part[e] = (ps[row * 96 + L] + ps[row * 96 + L + 32]) + ps[row * 96 + L + 64];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[e] += __shfl_xor(part[e], 2, 64);   // lanes L and L ^ 16
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[e] += __shfl_xor(part[e], 1, 64);   // L ^ 8
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[e] += part[e + 4];                  // L ^ 4
+        part[0] += part[2]; part[1] += part[3];                              // L ^ 2
+        part[0] += part[1];                                                  // L ^ 1
+        if (qd == 0) tot[row] = part[0];
+      }
+      __syncthreads();
+      float g[3][8];
+#pragma unroll
+      for (int np = 0; np < 3; ++np) {
+        const float4 g0 = *(const float4*)(ln_w + wave * 96 + np * 32 + hcol), g1 = *(const float4*)(ln_w + wave * 96 + np * 32 + hcol + 4);
+        g[np][0] = g0.x; g[np][1] = g0.y; g[np][2] = g0.z; g[np][3] = g0.w;
+        g[np][4] = g1.x; g[np][5] = g1.y; g[np][6] = g1.z; g[np][7] = g1.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int row = 16 * i + frow, m = m0 + row;
+        const float r = 1.0f / sqrtf(tot[row] / (float)R_N + eps);
+#pragma unroll
+        for (int np = 0; np < 3; ++np) {
+          u32x4_t y;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(hb[i][np][j] << 16), hi = __uint_as_float(hb[i][np][j] & 0xffff0000u);
+            y[j] = pk2(g[np][2 * j] * (lo * r), g[np][2 * j + 1] * (hi * r));
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(y, rx, m < M ? (unsigned)(m * R_N + wave * 96 + np * 32 + hcol) * 2u : OOB, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    return;
+  }
   // this lane owns row (lane & 15) of each 16-row tile and columns 96w + 16j + 4*fq .. +3 of each column tile
   const unsigned col_b = (unsigned)(wave * 96 + 4 * fq) * 4u;
   float* red = (float*)(smem + R_RED);
@@ -252,6 +363,28 @@ bool rowpanel_supports(int M, int N, int K, const void* A, const void* W, const 
   return true;
 }
 
+int launch_gemm_resid_norm_h(const void* A, const void* W, void* hidden, const float* ln_w, void* xn, int M, int K,
+                             float eps, hipStream_t st) {
+  DARK_CHECK_ARG(A && W && hidden && (ln_w == nullptr) == (xn == nullptr), "gemm_resid_norm_h: null operand");
+  DARK_CHECK_ARG(rowpanel_supports(M, R_N, K, A, W, hidden, ln_w, xn), "gemm_resid_norm_h: unsupported shape M=%d K=%d", M, K);
+  const int grid = cdiv(M, R_BM);
+  const unsigned a_bytes = (unsigned)((int64_t)M * K * 2), w_bytes = (unsigned)((int64_t)R_N * K * 2);
+  const unsigned h_bytes = (unsigned)((int64_t)M * R_N * 2), x_bytes = (unsigned)((int64_t)M * R_N * 2);
+  if (ln_w) {
+    static SmemOptIn optin;
+    DARK_TRY(optin.ensure((const void*)gemm_bf16_rowpanel<true, true>, R_SMEM, st));
+    hipLaunchKernelGGL((gemm_bf16_rowpanel<true, true>), dim3(grid), dim3(512), R_SMEM, st, (const bf16_t*)A, (const bf16_t*)W,
+                       hidden, ln_w, (bf16_t*)xn, M, K, eps, a_bytes, w_bytes, h_bytes, x_bytes);
+  } else {
+    static SmemOptIn optin;
+    DARK_TRY(optin.ensure((const void*)gemm_bf16_rowpanel<false, true>, R_SMEM, st));
+    hipLaunchKernelGGL((gemm_bf16_rowpanel<false, true>), dim3(grid), dim3(512), R_SMEM, st, (const bf16_t*)A, (const bf16_t*)W,
+                       hidden, ln_w, (bf16_t*)xn, M, K, eps, a_bytes, w_bytes, h_bytes, 0u);
+  }
+  DARK_CHECK_LAUNCH();
+  return DARK_OK;
+}
+
 int launch_gemm_resid_norm(const void* A, const void* W, float* hidden, const float* ln_w, void* xn, int M, int K,
                            float eps, hipStream_t st) {
   DARK_CHECK_ARG(A && W && hidden && (ln_w == nullptr) == (xn == nullptr), "gemm_resid_norm: null operand");
@@ -263,12 +396,12 @@ int launch_gemm_resid_norm(const void* A, const void* W, float* hidden, const fl
     static SmemOptIn optin;
     DARK_TRY(optin.ensure((const void*)gemm_bf16_rowpanel<true>, R_SMEM, st));
     hipLaunchKernelGGL((gemm_bf16_rowpanel<true>), dim3(grid), dim3(512), R_SMEM, st, (const bf16_t*)A, (const bf16_t*)W,
-                       hidden, ln_w, (bf16_t*)xn, M, K, eps, a_bytes, w_bytes, h_bytes, x_bytes);
+                       (void*)hidden, ln_w, (bf16_t*)xn, M, K, eps, a_bytes, w_bytes, h_bytes, x_bytes);
   } else {
     static SmemOptIn optin;
     DARK_TRY(optin.ensure((const void*)gemm_bf16_rowpanel<false>, R_SMEM, st));
     hipLaunchKernelGGL((gemm_bf16_rowpanel<false>), dim3(grid), dim3(512), R_SMEM, st, (const bf16_t*)A, (const bf16_t*)W,
-                       hidden, ln_w, (bf16_t*)xn, M, K, eps, a_bytes, w_bytes, h_bytes, 0u);
+                       (void*)hidden, ln_w, (bf16_t*)xn, M, K, eps, a_bytes, w_bytes, h_bytes, 0u);
   }
   DARK_CHECK_LAUNCH();
   return DARK_OK;

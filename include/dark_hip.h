@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DARK_HIP_ABI_VERSION 6
+#define DARK_HIP_ABI_VERSION 7
 
 #define DARK_OK 0
 #define DARK_ERR_ARG 1         /* bad shape / pointer / unsupported size */
@@ -459,13 +459,19 @@ int dark_dbg_gemm_head(const void* A, const void* W, void* records, int M, int N
  * DreamRMSNorm of modeling_dream_length.py:384/:451/:69-74 (attention) and :222/:458 (MLP). */
 int dark_dbg_gemm_resid_norm(const void* A, const void* W, float* hidden, const float* ln_w, void* xn, int M, int K,
                              float eps, void* stream);
+/* The same kernel on a bf16 residual stream (hidden [M,768] bf16, in place): out = bf16(float(hidden) + acc), one
+ * rounding, and xn = RMSNorm of the ROUNDED row -- hidden and xn are bit-identical to dark_dbg_gemm(epi 8) followed by
+ * dark_dbg_rmsnorm on the bf16 stream (the sum of squares is rebuilt in that kernel's order). */
+int dark_dbg_gemm_resid_norm_h(const void* A, const void* W, void* hidden, const float* ln_w, void* xn, int M, int K,
+                               float eps, void* stream);
 /* Which bf16 GEMM kernel dark_dbg_gemm and the forward use (A/B measurements and tests):
  *   0 = the library's choice per shape;
  *   1 = always the 128-row kernels of gemm.hip (and the unfused head);
  *   2 = the persistent 256 x 256 kernel wherever it supports the shape;
  *   4 = its staggered two-group form (gemm_bf16_s256) wherever it supports the shape, automatic tile height;
  *   8 / 9 / 10 = the same with the tile height forced to 256 / 288 / 320 rows;
- *   5 = the library's choice + the row-panel kernel for the residual projections (fp32 residual stream only);
+ *   5 = the library's choice + the row-panel kernel for both residual projections (either stream dtype);
+ *   13 = the library's choice + the row-panel kernel for o_proj only (bf16 residual stream);
  *   6 / 7 / 11 = the library's choice without its one-round down_proj routing / without q/k/v on the persistent
  *   kernel / with o_proj there too (the in-loop A/Bs recorded in DESIGN.md);
  *   12 = the library's GEMM choice with the N <= 128 attention instance's staging loads issued per loop iteration

@@ -169,6 +169,35 @@ def test_gemm_rowpanel_resid_norm(lib, M, K):
     assert lib.dark_dbg_gemm_resid_norm(H.ptr(A), H.ptr(W), H.ptr(h3), H.ptr(gam), None, M, K, eps, _s()) == H.DARK_ERR_ARG
 
 
+@pytest.mark.parametrize("M,K", [(1, 192), (95, 192), (96, 384), (333, 768), (2049, 3072), (23552, 768)])
+def test_gemm_rowpanel_bf16_stream_is_bit_identical(lib, M, K):
+    """Round 3: the row-panel kernel on a bf16 residual stream gives the SAME BITS as the residual GEMM (epi 8) followed
+    by rmsnorm_h16_kernel -- hidden and xn -- because it rebuilds that kernel's sum of squares in its order; rows beyond
+    M are never written."""
+    H = _hip()
+    d, eps = 768, 1e-6
+    g = torch.Generator().manual_seed(M * 5 + K)
+    A = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    W = (torch.randn(d, K, generator=g) * 0.05).bfloat16().to(DEV)
+    h0 = torch.randn(M + 2, d, generator=g).bfloat16().to(DEV)
+    gam = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    h1, h2, h3 = h0.clone(), h0.clone(), h0.clone()
+    x1 = torch.full((M + 2, d), 3.0, device=DEV, dtype=torch.bfloat16)
+    x2 = torch.full((M, d), 3.0, device=DEV, dtype=torch.bfloat16)
+    H.check(lib.dark_dbg_gemm_resid_norm_h(H.ptr(A), H.ptr(W), H.ptr(h1), H.ptr(gam), H.ptr(x1), M, K, eps, _s()))
+    H.check(lib.dark_dbg_set_gemm_variant(1))   # the 128-row residual GEMM (the persistent one gives the same bits)
+    H.check(lib.dark_dbg_gemm(H.DARK_BF16, 8, H.ptr(A), H.ptr(W), None, H.ptr(h2), M, d, K, d, _s()))
+    H.check(lib.dark_dbg_set_gemm_variant(0))
+    H.check(lib.dark_dbg_rmsnorm(H.DARK_BF16, H.DARK_BF16, H.ptr(h2), H.ptr(gam), H.ptr(x2), None, M, M, d, eps, _s()))
+    H.check(lib.dark_dbg_gemm_resid_norm_h(H.ptr(A), H.ptr(W), H.ptr(h3), None, None, M, K, eps, _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(h1.view(torch.int16), h2.view(torch.int16)) and torch.equal(h3.view(torch.int16), h2.view(torch.int16))
+    assert torch.equal(h1[M:], h0[M:]) and bool((x1[M:] == 3.0).all()), "rows beyond M must stay untouched"
+    assert torch.equal(x1[:M].view(torch.int16), x2.view(torch.int16)), "xn must equal the separate norm kernel's bit for bit"
+    ref = O.rms_norm(h1[:M].float().cpu(), gam.cpu(), eps)
+    np.testing.assert_allclose(x1[:M].cpu().float().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+
+
 # --------------------------------------------------------------------------- elementwise
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_embed_and_rmsnorm(lib, dtype):
