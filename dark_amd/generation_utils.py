@@ -428,7 +428,10 @@ class DreamGenerationMixin:
             return
         noise = philox = None
         if temperature > 0 and M > 0:
-            if noise_fn is None and ctx.lazy_noise:
+            # lazy noise (the draws evaluated inside the sampler) unless the rows are flat, where one Philox call per
+            # kept token costs more than the [M, V] fill it replaces (HipState.note_entropy); a step that samples
+            # nothing only reserves the generator offsets.  Same stream, same bits either way.
+            if noise_fn is None and ctx.lazy_noise and (not st.flat_rows or (skip and k == 0)):
                 philox = philox_fill_plan(x.device, M * V)
             else:
                 noise = self._draw_noise(step, M, V, x.device, noise_fn)
@@ -440,6 +443,8 @@ class DreamGenerationMixin:
             conf, x0 = ctx.head.head_and_sample(st, M, temperature, top_p, top_k, conf_mode, noise, philox)
         else:
             conf, x0 = st.head_and_sample(M, temperature, top_p, top_k, conf_mode, noise, philox)
+        if conf_mode == _hip.CONF_NEG_ENTROPY and temperature > 0 and noise_fn is None and ctx.lazy_noise:
+            st.note_entropy(conf, M)
         if trace is not None:
             trace.setdefault("confidence", []).append(conf.clone())
             trace.setdefault("x0", []).append(x0.clone())

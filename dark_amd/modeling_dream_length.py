@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import math
 import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -154,6 +155,10 @@ class HipState:
         self.head_stats = torch.zeros(2, dtype=torch.int32, device=dev)  # [rows sampled, rows that needed their logits]
         self.head_stats_host = torch.zeros(2, dtype=torch.int32).pin_memory()
         self.head_stats_event = None
+        # flat-row statistic of the lazy-noise policy (note_entropy): mean -confidence of the last sampled step
+        self.flat_rows = False
+        self.ent_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+        self.ent_event = None
         self._stats_seen = (0, 0)
         self._fuse_calls, self._fuse_off_until = 0, 0
         self.conf = torch.empty(rows, dtype=torch.float32, device=dev)
@@ -284,6 +289,26 @@ class HipState:
                                              noise.stride(0) if noise is not None else 0, _hip.ptr(conf),
                                              _hip.ptr(x0), self._s()))
         return conf, x0
+
+    # exp(mean entropy) above which the Exp(1) noise is materialised instead of evaluated inside the sampler: the lazy
+    # form costs one Philox4x32-10 call per KEPT token (a row as flat as T = 0.5 makes random-init logits keeps ~9 000
+    # of 15 080: 2.41 ms per 16 896 rows against 1.66 ms + a 0.11 ms fill, profiles/r03r_sampler_flat_rows_phases.txt),
+    # the materialised form one [M, V] fill and read whatever is kept; break-even is near 2 000 kept tokens a row
+    FLAT_ROWS_KEPT = 2000.0
+
+    def note_entropy(self, conf: torch.Tensor, M: int) -> None:
+        """Policy statistic only (no result depends on it: both noise forms give the same bits): the mean confidence of
+        an entropy-mode step is read back without waiting; `flat_rows` follows one or two steps behind."""
+        ev = self.ent_event
+        if ev is not None:
+            if not ev.query():
+                return
+            self.flat_rows = float(-self.ent_host[0]) > math.log(self.FLAT_ROWS_KEPT)
+            self.ent_event = None
+        if M > 0:
+            self.ent_host.copy_(conf[:M].mean().reshape(1), non_blocking=True)
+            self.ent_event = torch.cuda.Event()
+            self.ent_event.record(torch.cuda.current_stream(self.pk.device))
 
     def _use_fused_head(self) -> bool:
         if self.fused_head != "auto":

@@ -481,6 +481,38 @@ def test_think_sample_matches_reference(mini, golden_meta):
     assert exact >= 2, exact                                          # == the reference's goldens end to end
 
 
+def test_flat_rows_switch_the_noise_form_invisibly(golden_meta):
+    """Round 3: on flat rows (T = 0.5 on random-init logits: thousands of kept tokens a row) the loop materialises the
+    Exp(1) noise instead of evaluating Philox per kept token (HipState.note_entropy).  The switch happens mid-call, one
+    or two steps behind the statistic; sequences, histories and the generator offset are those of either pure form."""
+    cfg = DreamConfig(**dict(golden_meta["real"], num_hidden_layers=2))
+    m = DreamModel_length(cfg)
+    m.load_state_dict(synth.make_weights(cfg, seed=0), strict=True)
+    m = m.to(DEV).to(torch.bfloat16)
+    gen = torch.cuda.default_generators[0]
+    ids = synth.make_inputs(64, "ded", seed=4).to(DEV)
+    kw = dict(steps=12, temperature=0.5, alg="entropy", alg_temp=0, top_p=0.9, skip_noop_steps=False,
+              return_dict_in_generate=True, output_history=True)
+    outs, offs, flat = [], [], []
+    for lazy in (True, False, True):
+        for st in m._states.values():
+            st.flat_rows, st.ent_event = False, None
+        torch.manual_seed(21)
+        o = m.diffusion_generate(ids, generation_config=_gc(45), lazy_noise=lazy, **kw)
+        torch.cuda.synchronize()
+        outs.append(torch.stack(o.history))
+        offs.append(gen.get_offset())
+        flat.append(any(st.flat_rows for st in m._states.values()))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and offs[0] == offs[1] == offs[2]
+    assert flat[0] and flat[2], "the flat-row statistic never fired on rows this flat"
+    # peaked rows keep the lazy form
+    for st in m._states.values():
+        st.flat_rows, st.ent_event = False, None
+    m.diffusion_generate(ids, generation_config=_gc(45), **dict(kw, temperature=0.02))
+    torch.cuda.synchronize()
+    assert not any(st.flat_rows for st in m._states.values())
+
+
 def test_lazy_noise_is_invisible(golden_meta):
     """`lazy_noise=True` (draws computed in the sampler from torch's Philox stream) and `lazy_noise=False` (the
     [M, V] exponential_ fill the reference makes) give the same sequences and leave the generator at the same

@@ -19,11 +19,11 @@ def rep(old, new):
     src = src.replace(old, new)
 
 
-rep('\n__global__ __launch_bounds__(ST) void sample_kernel(',
+rep('\ntemplate <bool GROW>\n__device__ __forceinline__ void sample_row(',
     '\n__device__ unsigned long long g_ts[32768 * 10];\n'
     '#define PROF(k) do { if (tid == 0 && m < 32768) g_ts[m * 10 + (k)] = wall_clock64(); } while (0)\n'
-    '__global__ __launch_bounds__(ST) void sample_kernel(')
-rep('  const float* lr = logits + (int64_t)m * ldl;\n', '  const float* lr = logits + (int64_t)m * ldl;\n  PROF(0);\n')
+    'template <bool GROW>\n__device__ __forceinline__ void sample_row(')
+rep('  const float* lr = logits + (int64_t)blockIdx.x * ldl;\n\n  // 1. temperature', '  const float* lr = logits + (int64_t)blockIdx.x * ldl;\n  PROF(0);\n\n  // 1. temperature')
 rep('  mx = block_max(mx, s, tid);\n\n  int list_c', '  PROF(1);\n  mx = block_max(mx, s, tid);\n  PROF(2);\n\n  int list_c')
 rep('    if (rc == 2) {', '    PROF(3);\n    if (rc == 2) {')
 rep('                       (unsigned long long)m * V, tid, conf + m, x0 + m);\n      return;',
@@ -34,7 +34,7 @@ rep('  const float Zf = (float)block_sum(zs, s, tid);\n', '  const float Zf = (f
 rep('  const float psum = (float)ps;\n  const float entropy = (float)ent;\n\n  // 5. draw',
     '  const float psum = (float)ps;\n  const float entropy = (float)ent;\n  PROF(6);\n\n  // 5. draw')
 rep('  // block arg-max, ties -> lowest index; merge', '  PROF(7);\n  // block arg-max, ties -> lowest index; merge')
-rep('    s->bin = bi;\n  }\n', '    s->bin = bi;\n  }\n  PROF(8);\n')
+rep('    s->bin = bi;\n  }\n  if (list && conf_mode', '    s->bin = bi;\n  }\n  PROF(8);\n  if (list && conf_mode')
 rep('}  // namespace dark\n', '}  // namespace dark\nextern "C" int dark_dbg_sample_ts(unsigned long long* out, int n) {\n'
     '  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dark::g_ts), sizeof(unsigned long long) * n) != hipSuccess;\n}\n')
 os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
@@ -42,6 +42,6 @@ open(os.path.join(CSRC, "build", "sample_prof.hip"), "w").write(src)
 hipcc = "/opt/rocm/bin/hipcc"
 subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I.", "-I../../include", "-c",
                        "build/sample_prof.hip", "-o", "build/sample_prof.o"], cwd=CSRC)
-objs = [f"build/{n}.o" for n in ("api", "gemm", "attn", "elementwise", "expand", "grpo", "layout")] + ["build/sample_prof.o"]
+objs = [f"build/{n}.o" for n in ("api", "gemm", "gemm256", "gemm_rowpanel", "attn", "elementwise", "expand", "grpo", "layout", "gpt2")] + ["build/sample_prof.o"]
 subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *objs, "-o", "../libdark_hip_prof.so"], cwd=CSRC)
 print("built dark_amd/libdark_hip_prof.so")

@@ -13,7 +13,8 @@ noise = torch.empty(M, V, device=dev).exponential_()
 conf = torch.empty(M, device=dev); x0 = torch.empty(M, dtype=torch.long, device=dev)
 raw = ctypes.CDLL(_hip.LIB_PATH)
 names = ["load", "block_max", "nucleus_crossing", "filter/list", "softmax Z", "p/entropy", "draw", "argmax+write"]
-for T, top_p, lazy in ((0.1, 0.9, True), (0.1, 0.9, False), (1.0, 0.9, True), (0.0, 0.0, False)):
+_hip.check(lib.dark_dbg_set_sampler_stages(1))   # the single-stage kernel carries the stamps
+for T, top_p, lazy in ((0.1, 0.9, True), (0.5, 0.9, True), (0.5, 0.9, False), (1.0, 0.9, True), (0.0, 0.0, False)):
     def run():
         if lazy:
             _hip.check(lib.dark_sample_rows_philox(_hip.ptr(logits), V, M, V, T, top_p, 0, 2, 1234, 0, 256 * 2048, _hip.ptr(conf),
