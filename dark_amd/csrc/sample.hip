@@ -71,9 +71,12 @@ __device__ __forceinline__ unsigned long long mass_fx_nb(float l, float mx) {
   const unsigned long long m = (unsigned long long)(exp_neg(fmaxf(d, -MASS_RANGE)) * 1099511627776.0f);
   return d > -MASS_RANGE ? m : 0ull;
 }
-__device__ __forceinline__ int lin_bin(float l, float mx) {
-  const float d = (mx - l) * ((float)(NLIN - 1) / LIN_RANGE);  // monotone non-increasing in l
-  return d < (float)(NLIN - 1) ? (int)d : NLIN - 1;            // NaN / inf / huge -> last bin
+constexpr float LIN_SCALE = (float)(NLIN - 1) / LIN_RANGE;
+// (any positive scale gives a monotone map, and the search is exact whatever the bins are: a row known to be flat uses
+// bins over its own range, so that the crossing bin holds a few dozen elements instead of a few hundred)
+__device__ __forceinline__ int lin_bin(float l, float mx, float sc = LIN_SCALE) {
+  const float d = (mx - l) * sc;                      // monotone non-increasing in l
+  return d < (float)(NLIN - 1) ? (int)d : NLIN - 1;   // NaN / inf / huge -> last bin
 }
 
 struct Scratch {
@@ -97,6 +100,18 @@ __device__ __forceinline__ float block_max(float v, Scratch* s, int tid) {
 #pragma unroll
   for (int w = 1; w < NT / 64; ++w) r = fmaxf(r, s->f32a[w]);
   return r;
+}
+template <int NT = ST>
+__device__ __forceinline__ void block_max2(float& a, float& b, Scratch* s, int tid) {
+  a = wave_max(a);
+  b = wave_max(b);
+  __syncthreads();
+  if ((tid & 63) == 0) { s->f32a[tid >> 6] = a; s->f32b[tid >> 6] = b; }
+  __syncthreads();
+  a = s->f32a[0];
+  b = s->f32b[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) { a = fmaxf(a, s->f32a[w]); b = fmaxf(b, s->f32b[w]); }
 }
 template <int NT = ST>
 __device__ __forceinline__ uint32_t block_max_u32(uint32_t v, Scratch* s, int tid) {
@@ -272,8 +287,49 @@ __device__ int resolve_candidates(const uint32_t* cand, const unsigned long long
 __device__ int nucleus_crossing(const float* row, int V, float mx, float top_p, unsigned long long* hist,
                                 uint32_t* cand, unsigned long long* cfx, int* cidx, Scratch* s, int tid,
                                 uint32_t* tau, unsigned long long* above, int* n_tau, unsigned long long* Tout,
-                                int* head_c, bool defer_small) {
+                                int* head_c, bool defer_small, bool flat_hint, float mn) {
   *head_c = -1;
+  unsigned long long T;
+  float sc = LIN_SCALE;
+  if (flat_hint) {
+    const float span = fminf(LIN_RANGE, mx - mn);  // mn: the row minimum (only read here)
+    if (span > 0.f) sc = (float)(NLIN - 1) / span;
+    // The first stage already found this row flat (more than SH pieces within reach of the maximum): the head path
+    // cannot resolve it, so the pass that sums the masses fills the histogram as well -- the same integers summed
+    // in another order, one exp pass and the candidate atomics less.
+    for (int i = tid; i < NLIN; i += ST) hist[i] = 0;
+    if (tid == 0) s->ncand = 0;
+    __syncthreads();
+    unsigned long long zl = 0;
+    const int v4 = V >> 2;
+    for (int j0 = tid; j0 < v4; j0 += 2 * ST) {
+      float4 l4[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (j0 + u * ST < v4) l4[u] = *(const float4*)(row + 4 * (j0 + u * ST));
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (j0 + u * ST < v4) {
+          const float le[4] = {l4[u].x, l4[u].y, l4[u].z, l4[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned long long fx = mass_fx_nb(le[e], mx);
+            zl += fx;
+            if (fx) atomicAdd(&hist[lin_bin(le[e], mx, sc)], fx);
+          }
+        }
+      }
+    }
+    for (int i = 4 * v4 + tid; i < V; i += ST) {
+      const float l = row[i];
+      const unsigned long long fx = mass_fx(l, mx);
+      zl += fx;
+      if (fx) atomicAdd(&hist[lin_bin(l, mx, sc)], fx);
+    }
+    zl = block_sum_u64(zl, s, tid);  // (its barriers also publish the histogram)
+    T = (unsigned long long)((double)top_p * (double)zl);  // floor
+    *Tout = T;
+  } else {
   // ---- head path: the pass that sums the masses also gathers the elements within HEAD_RANGE of the
   // maximum; when they hold more than top_p of the mass (any peaked row) the crossing is among them
   if (tid == 0) s->ncand = 0;
@@ -327,13 +383,13 @@ __device__ int nucleus_crossing(const float* row, int V, float mx, float top_p, 
   }
   block_sum2_u64(zl, hl, s, tid);  // (its barriers also publish the candidates)
   const unsigned long long Z = zl;
-  const unsigned long long T = (unsigned long long)((double)top_p * (double)Z);  // floor
+  T = (unsigned long long)((double)top_p * (double)Z);  // floor
   *Tout = T;
-  int c = s->ncand;
-  if (c <= CAND_CAP && hl > T) {  // c <= CAND_CAP: every gathered element has a slot, hl is their total mass
-    *head_c = c;
-    if (defer_small && c <= 64) return 2;
-    return resolve_candidates(cand, cfx, c, 0ull, T, s, tid, tau, above, n_tau);
+  const int ch = s->ncand;
+  if (ch <= CAND_CAP && hl > T) {  // ch <= CAND_CAP: every gathered element has a slot, hl is their total mass
+    *head_c = ch;
+    if (defer_small && ch <= 64) return 2;
+    return resolve_candidates(cand, cfx, ch, 0ull, T, s, tid, tau, above, n_tau);
   }
   // ---- general path: mass histogram over linear bins, then the elements of the crossing bin
   for (int i = tid; i < NLIN; i += ST) hist[i] = 0;
@@ -345,20 +401,33 @@ __device__ int nucleus_crossing(const float* row, int V, float mx, float top_p, 
     if (fx) atomicAdd(&hist[lin_bin(l, mx)], fx);
   }
   __syncthreads();
+  }  // !flat_hint
   scan_crossing(hist, NLIN, 0, +1, 0ull, T, s, tid);
   __syncthreads();
   if (!s->found) return 0;
   const int b = s->bin;
   const unsigned long long A = s->above;
-  for (int i = tid; i < V; i += ST) {
-    const float l = row[i];
-    if (lin_bin(l, mx) == b) {
+  auto take = [&](float l) {
+    if (lin_bin(l, mx, sc) == b) {
       const int slot = atomicAdd(&s->ncand, 1);
       if (slot < CAND_CAP) { cand[slot] = fkey(l); cfx[slot] = mass_fx(l, mx); }
     }
+  };
+  {  // 16-byte reads, two in flight (which thread records which element does not matter: resolve_candidates sums)
+    const int v4 = V >> 2;
+    for (int j0 = tid; j0 < v4; j0 += 2 * ST) {
+      float4 l4[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (j0 + u * ST < v4) l4[u] = *(const float4*)(row + 4 * (j0 + u * ST));
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (j0 + u * ST < v4) { take(l4[u].x); take(l4[u].y); take(l4[u].z); take(l4[u].w); }
+    }
+    for (int i = 4 * v4 + tid; i < V; i += ST) take(row[i]);
   }
   __syncthreads();
-  c = s->ncand;
+  const int c = s->ncand;
   if (c > CAND_CAP) return -1;
   return resolve_candidates(cand, cfx, c, A, T, s, tid, tau, above, n_tau);
 }
@@ -513,8 +582,8 @@ __global__ __launch_bounds__(SH) void sample_head_kernel(const float* __restrict
   __shared__ Scratch sc;
   Scratch* s = &sc;
   const int tid = threadIdx.x, m = blockIdx.x;
-  auto give_up = [&]() {  // block-uniform: x0 = -1 hands the row to the second stage
-    if (tid == 0) x0[m] = -1;
+  auto give_up = [&](int64_t mark = -1) {  // block-uniform: x0 = -1 hands the row to the second stage (-2: and it is flat)
+    if (tid == 0) x0[m] = mark;
   };
   if (tid == 0) s->ncand = 0;
 
@@ -553,7 +622,7 @@ __global__ __launch_bounds__(SH) void sample_head_kernel(const float* __restrict
     c4 = 0;
 #pragma unroll
     for (int w = 0; w < SH / 64; ++w) c4 += s->i32[w];
-    if (c4 > SH) { give_up(); return; }
+    if (c4 > SH) { give_up(-2); return; }
   }
   if (temperature > 0.f) {
 #pragma unroll
@@ -701,7 +770,8 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ logits, int
                                            const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
                                            float* __restrict__ conf, int64_t* __restrict__ x0,
                                            const int32_t* __restrict__ row_ids,
-                                           const int32_t* __restrict__ n_dev, float* __restrict__ row_ws) {
+                                           const int32_t* __restrict__ n_dev, float* __restrict__ row_ws,
+                                           bool flat_hint = false) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (n_dev && (int)blockIdx.x >= *n_dev) return;  // row count from device memory (block-uniform)
   const int vp = (V + 3) & ~3;
@@ -718,8 +788,8 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ logits, int
   const int m = row_ids ? row_ids[blockIdx.x] : blockIdx.x;
   const float* lr = logits + (int64_t)blockIdx.x * ldl;
 
-  // 1. temperature (generation_utils.py:60-61) and row max
-  float mx = -INFINITY;
+  // 1. temperature (generation_utils.py:60-61) and row max (a row the first stage found flat: its minimum too, negated)
+  float mx = -INFINITY, nmn = -INFINITY;
   if ((ldl & 3) == 0 && ((uintptr_t)logits & 15) == 0) {
     // the row is the only HBM traffic of this kernel: a thread's loads are issued back to back, eight at a time
     // (one at a time, each iteration waits out a full memory latency: 58 % of the wave cycles were spent so)
@@ -740,6 +810,7 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ logits, int
           if (temperature > 0.f) { l.x = l.x / temperature; l.y = l.y / temperature; l.z = l.z / temperature; l.w = l.w / temperature; }
           *(float4*)(row + 4 * i) = l;
           mx = fmaxf(fmaxf(mx, fmaxf(l.x, l.y)), fmaxf(l.z, l.w));
+          if (flat_hint) nmn = fmaxf(fmaxf(nmn, fmaxf(-l.x, -l.y)), fmaxf(-l.z, -l.w));
         }
       }
     }
@@ -748,6 +819,7 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ logits, int
       if (temperature > 0.f) l = l / temperature;
       row[i] = l;
       mx = fmaxf(mx, l);
+      nmn = fmaxf(nmn, -l);
     }
   } else {
     for (int i = tid; i < V; i += ST) {
@@ -755,11 +827,14 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ logits, int
       if (temperature > 0.f) l = l / temperature;
       row[i] = l;
       mx = fmaxf(mx, l);
+      nmn = fmaxf(nmn, -l);
     }
   }
-  mx = block_max(mx, s, tid);
+  if (flat_hint) block_max2(mx, nmn, s, tid);  // (block-uniform)
+  else mx = block_max(mx, s, tid);
 
   int list_c = -1;   // >= 0: list mode (see below)
+  uint32_t cut = 0;  // keys below this are filtered (applied inside the softmax pass; 0 = nothing)
   int my_idx = 0;    // list mode: vocabulary index of this thread's candidate
   float my_e = 0.f;  // list mode: exp(l - max) of this thread's candidate if it is kept, else 0
 
@@ -770,7 +845,7 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ logits, int
     int n_tau = 0;
     int head_c = -1;
     int rc = nucleus_crossing(row, V, mx, top_p, hist, cand, cfx, cidx, s, tid, &tau, &above, &n_tau, &T, &head_c,
-                              !(top_k > 0 && top_k < V));
+                              !(top_k > 0 && top_k < V), flat_hint, -nmn);
     if (rc == 2) {  // block-uniform: waves 1..7 are done, wave 0 finishes the row without further barriers
       if (tid < 64)
         list_tail_wave(cand, cfx, cidx, head_c, T, mx, V, temperature, conf_mode, noise + (int64_t)m * ldn, pn,
@@ -800,8 +875,12 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ logits, int
           if (keep) my_e = exp_neg(fkey_inv(kj) - mx);
         }
       } else if (t_keep >= (unsigned long long)n_tau) {
-        for (int i = tid; i < V; i += ST)
-          if (fkey(row[i]) < tau) row[i] = DARK_FLT_LOWEST;
+        if (top_k > 0 && top_k < V) {
+          for (int i = tid; i < V; i += ST)
+            if (fkey(row[i]) < tau) row[i] = DARK_FLT_LOWEST;
+        } else {
+          cut = tau;  // no pass of its own: the softmax pass below gives these elements the 0 that finfo.min would
+        }
       } else {
         // some, not all, of the equal-valued boundary elements are kept: the first t_keep by index
         const int chunk = (V + ST - 1) / ST;
@@ -853,14 +932,25 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ logits, int
   if (list) {
     zs = (double)my_e;
   } else {
-    for (int i = tid; i < V; i += ST) {
-      const float d = row[i] - mx;
-      float e = 0.f;
-      if (d > -104.f) {  // exp(-104) < 2^-149: exactly 0 in fp32 below
-        e = exp_neg(d);
-        zs += (double)e;
+    // (here and in the two passes below: four of a thread's elements per trip, their reads issued together; the
+    // elements are visited in the same order, so every sum is the same sum)
+    for (int i0 = tid; i0 < V; i0 += 4 * ST) {
+      float lv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) lv[u] = i0 + u * ST < V ? row[i0 + u * ST] : -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * ST;
+        if (i < V) {
+          const float d = lv[u] - mx;
+          float e = 0.f;
+          if (d > -104.f && fkey(lv[u]) >= cut) {  // exp(-104) < 2^-149: exactly 0 in fp32 below
+            e = exp_neg(d);
+            zs += (double)e;
+          }
+          row[i] = e;
+        }
       }
-      row[i] = e;
     }
   }
   const float Zf = (float)block_sum(zs, s, tid);
@@ -880,15 +970,22 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ logits, int
       besti = my_idx;
     }
   } else {
-    for (int i = tid; i < V; i += ST) {
-      const float e = row[i];
-      if (e > 0.f) {
-        const float p = e / Zf;
-        row[i] = p;
-        ps += (double)p;
-        if (conf_mode == DARK_CONF_NEG_ENTROPY) ent += (double)(p * log_pos(p + 1e-10f));
-        if (p > t1) { t2 = t1; t1 = p; } else if (p > t2) { t2 = p; }
-        if (p > bestp) { bestp = p; besti = i; }
+    for (int i0 = tid; i0 < V; i0 += 4 * ST) {
+      float ev[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ev[u] = i0 + u * ST < V ? row[i0 + u * ST] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * ST;
+        const float e = ev[u];
+        if (e > 0.f) {
+          const float p = e / Zf;
+          row[i] = p;
+          ps += (double)p;
+          if (conf_mode == DARK_CONF_NEG_ENTROPY) ent += (double)(p * log_pos(p + 1e-10f));
+          if (conf_mode == DARK_CONF_MARGIN) { if (p > t1) { t2 = t1; t1 = p; } else if (p > t2) { t2 = p; } }
+          if (!(temperature > 0.f) && p > bestp) { bestp = p; besti = i; }  // (with T > 0 the draw below decides)
+        }
       }
     }
   }
@@ -915,15 +1012,32 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ logits, int
         pq = (q0 + tid) / pn.nthreads;
         pt = (unsigned int)(q0 + tid - pq * pn.nthreads);
       }
-      for (int i = tid; i < V; i += ST) {
-        const float p = row[i];
-        if (p > 0.f) {
-          const float r = (p / psum) / (pn.nthreads ? philox_exponential_qt(pn, pq, pt) : qr[i]);
-          if (r > bestp) { bestp = r; besti = i; }
-        }
-        if (pn.nthreads) {
+      if (pn.nthreads) {
+        for (int i = tid; i < V; i += ST) {
+          const float p = row[i];
+          if (p > 0.f) {
+            const float r = (p / psum) / philox_exponential_qt(pn, pq, pt);
+            if (r > bestp) { bestp = r; besti = i; }
+          }
           pt += ST;  // pt < nthreads and ST < 2^31: no wrap
           while (pt >= pn.nthreads) { pt -= pn.nthreads; ++pq; }
+        }
+      } else {
+        // the noise of the kept positions of four trips is requested before the first quotient is formed (one trip at
+        // a time, every trip waited out a memory latency: this pass was a fifth of a flat row's lifetime)
+        for (int i0 = tid; i0 < V; i0 += 4 * ST) {
+          float pv[4], qv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) pv[u] = i0 + u * ST < V ? row[i0 + u * ST] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) qv[u] = pv[u] > 0.f ? qr[i0 + u * ST] : 1.f;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (pv[u] > 0.f) {
+              const float r = (pv[u] / psum) / qv[u];
+              if (r > bestp) { bestp = r; besti = i0 + u * ST; }
+            }
+          }
         }
       }
     }
@@ -970,19 +1084,27 @@ __device__ __forceinline__ void sample_row(const float* __restrict__ logits, int
   }
 }
 
-__global__ __launch_bounds__(ST) void sample_kernel(const float* __restrict__ logits, int64_t ldl, int V,
+// (six waves per SIMD = two workgroups per CU, which is what the row's LDS allows: the register budget is 80)
+__global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void sample_kernel(const float* __restrict__ logits, int64_t ldl, int V,
                                                     float temperature, float top_p, int top_k, int conf_mode,
                                                     const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
                                                     float* __restrict__ conf, int64_t* __restrict__ x0,
                                                     const int32_t* __restrict__ row_ids,
                                                     const int32_t* __restrict__ n_dev, int second_stage) {
-  // second_stage (of the two-stage sampler): only the rows sample_head_kernel marked with x0 = -1; the other workgroups
+  // second_stage (of the two-stage sampler): only the rows sample_head_kernel marked with x0 = -1 / -2; the other workgroups
   // return at once (12 us for 16 896 of them)
-  if (second_stage && x0[blockIdx.x] != -1) return;
-  sample_row<false>(logits, ldl, V, temperature, top_p, top_k, conf_mode, noise, ldn, pn, conf, x0, row_ids, n_dev, nullptr);
+  // (-2: a row the first stage found flat)
+  bool flat = false;
+  if (second_stage) {
+    const int64_t mark = x0[blockIdx.x];
+    if (mark != -1 && mark != -2) return;
+    flat = mark == -2;
+  }
+  sample_row<false>(logits, ldl, V, temperature, top_p, top_k, conf_mode, noise, ldn, pn, conf, x0, row_ids, n_dev, nullptr,
+                    flat);
 }
 
-__global__ __launch_bounds__(ST) void sample_bigv_kernel(const float* __restrict__ logits, int64_t ldl, int V,
+__global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void sample_bigv_kernel(const float* __restrict__ logits, int64_t ldl, int V,
                                                          float temperature, float top_p, int top_k, int conf_mode,
                                                          const float* __restrict__ noise, int64_t ldn, PhiloxNoise pn,
                                                          float* __restrict__ conf, int64_t* __restrict__ x0,
@@ -1088,7 +1210,7 @@ int launch_sample_indexed(const float* logits, int64_t ldl, int M, int V, float 
       const hipError_t e2 = hipGetLastError();
       if (e2 != hipSuccess) {
         set_error("sample_rows: the second stage of the two-stage sampler could not be launched (%s): conf / x0 are "
-                  "UNDEFINED for this call (rows the first stage did not finish hold x0 = -1) and must not be committed",
+                  "UNDEFINED for this call (rows the first stage did not finish hold x0 = -1 or -2) and must not be committed",
                   hipGetErrorString(e2));
         return DARK_ERR_HIP;
       }

@@ -24,7 +24,8 @@ rep('\ntemplate <bool GROW>\n__device__ __forceinline__ void sample_row(',
     '#define PROF(k) do { if (tid == 0 && m < 32768) g_ts[m * 10 + (k)] = wall_clock64(); } while (0)\n'
     'template <bool GROW>\n__device__ __forceinline__ void sample_row(')
 rep('  const float* lr = logits + (int64_t)blockIdx.x * ldl;\n\n  // 1. temperature', '  const float* lr = logits + (int64_t)blockIdx.x * ldl;\n  PROF(0);\n\n  // 1. temperature')
-rep('  mx = block_max(mx, s, tid);\n\n  int list_c', '  PROF(1);\n  mx = block_max(mx, s, tid);\n  PROF(2);\n\n  int list_c')
+rep('  if (flat_hint) block_max2(mx, nmn, s, tid);  // (block-uniform)\n  else mx = block_max(mx, s, tid);\n\n  int list_c',
+    '  PROF(1);\n  if (flat_hint) block_max2(mx, nmn, s, tid);\n  else mx = block_max(mx, s, tid);\n  PROF(2);\n\n  int list_c')
 rep('    if (rc == 2) {', '    PROF(3);\n    if (rc == 2) {')
 rep('                       (unsigned long long)m * V, tid, conf + m, x0 + m);\n      return;',
     '                       (unsigned long long)m * V, tid, conf + m, x0 + m);\n'
@@ -35,7 +36,26 @@ rep('  const float psum = (float)ps;\n  const float entropy = (float)ent;\n\n  /
     '  const float psum = (float)ps;\n  const float entropy = (float)ent;\n  PROF(6);\n\n  // 5. draw')
 rep('  // block arg-max, ties -> lowest index; merge', '  PROF(7);\n  // block arg-max, ties -> lowest index; merge')
 rep('    s->bin = bi;\n  }\n  if (list && conf_mode', '    s->bin = bi;\n  }\n  PROF(8);\n  if (list && conf_mode')
-rep('}  // namespace dark\n', '}  // namespace dark\nextern "C" int dark_dbg_sample_ts(unsigned long long* out, int n) {\n'
+# stamps inside nucleus_crossing (g_tx, read by dark_dbg_sample_tx): entry, [flat: zeroed, fused mass+histogram pass,
+# block sum | else: mass pass, block sum, histogram pass], scan, crossing-bin gather, resolve
+rep('\n__device__ int nucleus_crossing(',
+    '\n__device__ unsigned long long g_tx[32768 * 8];\n'
+    '#define PROFX(k) do { if (tid == 0 && blockIdx.x < 32768) g_tx[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)\n'
+    '__device__ int nucleus_crossing(')
+rep('  *head_c = -1;\n  unsigned long long T;\n', '  *head_c = -1;\n  unsigned long long T;\n  PROFX(0);\n')
+rep('    unsigned long long zl = 0;\n    const int v4 = V >> 2;\n', '    PROFX(1);\n    unsigned long long zl = 0;\n    const int v4 = V >> 2;\n')
+rep('    zl = block_sum_u64(zl, s, tid);  // (its barriers also publish the histogram)\n',
+    '    PROFX(2);\n    zl = block_sum_u64(zl, s, tid);\n    PROFX(3);\n')
+rep('  block_sum2_u64(zl, hl, s, tid);  // (its barriers also publish the candidates)\n',
+    '  PROFX(1);\n  block_sum2_u64(zl, hl, s, tid);\n  PROFX(2);\n')
+rep('  __syncthreads();\n  }  // !flat_hint\n', '  __syncthreads();\n  PROFX(3);\n  }  // !flat_hint\n')
+rep('  if (!s->found) return 0;\n  const int b = s->bin;', '  PROFX(4);\n  if (!s->found) return 0;\n  const int b = s->bin;')
+rep('  const int c = s->ncand;\n  if (c > CAND_CAP) return -1;\n  return resolve_candidates(cand, cfx, c, A, T, s, tid, tau, above, n_tau);',
+    '  const int c = s->ncand;\n  PROFX(5);\n  if (c > CAND_CAP) return -1;\n'
+    '  const int rr_ = resolve_candidates(cand, cfx, c, A, T, s, tid, tau, above, n_tau);\n  PROFX(6);\n  return rr_;')
+rep('}  // namespace dark\n', '}  // namespace dark\nextern "C" int dark_dbg_sample_tx(unsigned long long* out, int n) {\n'
+    '  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dark::g_tx), sizeof(unsigned long long) * n) != hipSuccess;\n}\n'
+    'extern "C" int dark_dbg_sample_ts(unsigned long long* out, int n) {\n'
     '  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dark::g_ts), sizeof(unsigned long long) * n) != hipSuccess;\n}\n')
 os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
 open(os.path.join(CSRC, "build", "sample_prof.hip"), "w").write(src)

@@ -15,8 +15,15 @@ dev = torch.device("cuda", 0)
 s = _hip.stream_ptr(dev)
 
 
+NOISE = {}
+
+
 def run(logits, V, T, top_p, mode, philox, two_stage, reps=5):
     M = logits.shape[0]
+    if "--mem-noise" in sys.argv:   # the materialised fill instead of the lazy Philox draw
+        if M not in NOISE:
+            NOISE[M] = torch.empty(M, logits.stride(0), device=dev).exponential_(generator=torch.Generator(device=dev).manual_seed(7))
+        return run_mem(logits, V, T, top_p, mode, NOISE[M], two_stage, reps)
     conf = torch.zeros(M, device=dev)
     x0 = torch.zeros(M, dtype=torch.long, device=dev)
     raw = lib.dark_sample_rows_philox
@@ -25,6 +32,24 @@ def run(logits, V, T, top_p, mode, philox, two_stage, reps=5):
     def go():
         _hip.check(raw(_hip.ptr(logits), logits.stride(0), M, V, T, top_p, 0, mode, philox[0], philox[1], philox[2],
                        _hip.ptr(conf), _hip.ptr(x0), s))
+    go()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        go()
+    torch.cuda.synchronize()
+    return conf.clone(), x0.clone(), (time.perf_counter() - t0) / reps * 1e3
+
+
+def run_mem(logits, V, T, top_p, mode, noise, two_stage, reps):
+    M = logits.shape[0]
+    conf = torch.zeros(M, device=dev)
+    x0 = torch.zeros(M, dtype=torch.long, device=dev)
+    _hip.check(lib.dark_dbg_set_sampler_stages(0 if two_stage else 1))
+
+    def go():
+        _hip.check(lib.dark_sample_rows(_hip.ptr(logits), logits.stride(0), M, V, T, top_p, 0, mode, _hip.ptr(noise),
+                                        noise.stride(0), _hip.ptr(conf), _hip.ptr(x0), s))
     go()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -43,7 +68,7 @@ def main():
                ("mixed", 16896, 15080, 0.554, 0.1),
                ("greedy T=0", 16896, 15080, 5.54, 0.0),
                ("dbpedia vocab", 8192, 25427, 0.554, 0.1))
-    for name, M, V, sigma, T in regimes[:int(sys.argv[1]) if len(sys.argv) > 1 else len(regimes)]:
+    for name, M, V, sigma, T in regimes[:int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else len(regimes)]:
         ld = (V + 3) & ~3
         buf = torch.zeros(M, ld)
         buf[:, :V] = torch.randn(M, V, generator=g) * sigma
@@ -58,7 +83,7 @@ def main():
             c0, x0, t0 = run(logits, V, T, 0.9, mode, philox, False)
             same = bool(torch.equal(c0.view(torch.int32), c1.view(torch.int32)) and torch.equal(x0, x1))
             print(f"{name:36s} mode {mode}: single-stage {t0:7.3f} ms   two-stage {t1:7.3f} ms   bit-identical {same}", flush=True)
-            assert same
+            assert same or "--no-assert" in sys.argv
 
 
 if __name__ == "__main__":
