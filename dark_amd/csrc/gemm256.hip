@@ -47,6 +47,22 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
 __device__ __forceinline__ float silu_hw(float g) {
   return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896340736f));
 }
+// silu(g) * u for four accumulator values at once, the same operations as silu_hw(g) * u with the multiplies and the
+// add on the packed fp32 pipe (v_pk_mul_f32 / v_pk_add_f32: two lanes' worth per instruction, same IEEE results): the
+// epilogue is VALU-bound and exposed, and the scalar form spent 160 of its 520 instructions on these.
+__device__ __forceinline__ void silu_mul4(const f32x4& g, const f32x4& u, float (&out)[4]) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x2_t g2 = {g[2 * h], g[2 * h + 1]}, u2 = {u[2 * h], u[2 * h + 1]};
+    const f32x2_t t = g2 * (f32x2_t){-1.44269504088896340736f, -1.44269504088896340736f};
+    const f32x2_t d = (f32x2_t){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + (f32x2_t){1.0f, 1.0f};
+    const f32x2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2_t o = (g2 * r) * u2;
+    out[2 * h] = o[0];
+    out[2 * h + 1] = o[1];
+  }
+}
 
 // Two horizontally adjacent 16 x 16 tiles of this lane's final values (row = lane & 15, columns cb + 16t + 4q + e)
 // as ONE 16-byte bf16 store per lane (see store_pair_bf16 in gemm.hip: one permlane16_swap per dword).
@@ -219,8 +235,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256(const bf16_t* __restrict__
         float v[2][4];
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[p][e] = silu_hw(acc[2 * p][mi][e]) * acc[2 * p + 1][mi][e];
+          silu_mul4(acc[2 * p][mi], acc[2 * p + 1][mi], v[p]);
         store_pair(v[0], v[1], (bf16_t*)out + mrow * ldo, (n0 + wn * 64) >> 1, row_ok ? (N >> 1) : 0, fq);
       } else if constexpr (EPI == EPI_BIAS) {
 #pragma unroll
@@ -594,8 +609,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         float v[2][4];
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[p][e] = silu_hw(acc[2 * p][mi][e]) * acc[2 * p + 1][mi][e];
+          silu_mul4(acc[2 * p][mi], acc[2 * p + 1][mi], v[p]);
         const uint32_t a_lo = pk_bf16(v[0][0], v[0][1]), a_hi = pk_bf16(v[0][2], v[0][3]);
         const uint32_t b_lo = pk_bf16(v[1][0], v[1][1]), b_hi = pk_bf16(v[1][2], v[1][3]);
         const auto sx = __builtin_amdgcn_permlane16_swap(a_lo, b_lo, false, false);
