@@ -77,6 +77,7 @@ __device__ __forceinline__ void store_pair(const float (&v0)[4], const float (&v
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) unsigned lds_u32;
 
 }  // namespace
 
@@ -536,8 +537,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   if constexpr (TUNE != 0) wait_batches(false, false);
   else if (NHI == 0 || !hi) __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSLO * (NB - 2)));
   else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSHI * (NB - 2)));
+  // TUNE bit 6 (decoupled groups): per-buffer arrival counters in LDS replace the two workgroup barriers per K-tile --
+  // fill[b] counts the waves whose DMA pieces of the K-tile in buffer b have landed, rel[b] the waves that have read
+  // it (both monotone: 8 per use of the buffer) -- so that a wave waits for the data it needs and for nothing else.
+  lds_u32* const cnt = (lds_u32*)(lds_void*)(smem + S_SMEM + (EPI == EPI_BIAS ? tilesN * 256 * 4 : 0));   // fill[NB], rel[NB]
+  if constexpr (TUNE & 64) {
+    if (tid < 2 * NB) cnt[tid] = 0u;
+  }
   __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one interval behind group 0
+  if constexpr (!(TUNE & 64)) {
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one interval behind group 0
+  }
 
   f32x4 acc[P_NI][MI];
   bf16x8 fa[MI], fw[P_NI];
@@ -718,6 +728,88 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
     if constexpr (PROBE & 8) return (long long)__builtin_readcyclecounter();
     else return 0;
   };
+  if constexpr (TUNE & 64) {
+    bool dead = false;   // a wait that never ends (a bug) must not hang the GPU: give up on all waits, results are wrong
+    auto spin = [&](const lds_u32* c, unsigned target) {
+      if (!dead) {
+        int guard = 0;
+        for (;;) {
+          const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)*(const volatile lds_u32*)c);
+          if (v >= target) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++guard > (1 << 18)) { dead = true; break; }
+        }
+      }
+      asm volatile("" ::: "memory");
+    };
+    auto signal = [&](lds_u32* c) {
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    lds_u32* const fill = cnt;
+    lds_u32* const rel = cnt + NB;
+    signal(fill + 0);                       // (this wave's pieces of K-tile 0: waited for above)
+    if (grp == 1) spin(fill + 1, 4u);       // the stagger: group 1 starts when group 0 has finished its first LOAD
+    unsigned gen8 = 8u;                     // 8 * (uses of buffer rbuf so far, this one included)
+    // the two counters an iteration depends on are read one MFMA phase early (the reads return while the MFMAs issue);
+    // only a value that is still short sends the wave into the polling loop
+    unsigned vf = 0u, vr = 0xffffffffu;     // fill[rbuf]; rel[d_buf] (nothing to release before the first batch)
+    for (int id = wg; id < ntiles; id += G) {
+      int tm, tn;
+      tile_of(id, tm, tn);
+      for (int kt = 0; kt < KT; ++kt) {
+        if (kt == 0 && pending) epilogue(pm0, pn0);
+        const int nbuf = rbuf + 1 == NB ? 0 : rbuf + 1;
+        // every wave's pieces of this K-tile are in LDS; every wave has read the K-tile whose buffer (d_buf = rbuf - 1)
+        // the next DMA batch overwrites
+        if (vf < gen8) spin(fill + rbuf, gen8);
+        if (vr < (rbuf == 0 ? gen8 - 8u : gen8)) spin(rel + d_buf, rbuf == 0 ? gen8 - 8u : gen8);
+        asm volatile("" ::: "memory");
+        {
+          const char* as = smem + rbuf * S_BUF + a_rd;
+          const char* ws = smem + rbuf * S_BUF + w_rd;
+#pragma unroll
+          for (int j = 0; j < P_NI; ++j) fw[j] = *(const bf16x8*)(ws + j * 1024);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(as + i * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        signal(rel + rbuf);   // (LDS operations of a wave execute in order: the add follows the reads)
+        stage_next();
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's pieces of the NEXT K-tile have landed (counted as in the lock-step loop below)
+        wait_batches(pending && kt < NB - 2, true);
+        signal(fill + nbuf);
+        // next iteration's counters: fill[nbuf] and rel[rbuf] (its d_buf), wanted at gen8' and at this gen8
+        vf = *(const volatile lds_u32*)(fill + nbuf);
+        vr = *(const volatile lds_u32*)(rel + rbuf);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt == 0) {
+#pragma unroll
+          for (int j = 0; j < P_NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < P_NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        vf = (unsigned)__builtin_amdgcn_readfirstlane((int)vf);
+        vr = (unsigned)__builtin_amdgcn_readfirstlane((int)vr);
+        rbuf = nbuf;
+        if (rbuf == 0) gen8 += 8u;
+      }
+      pm0 = tm * TM;
+      pn0 = tn * 256;
+      pending = true;
+    }
+    epilogue(pm0, pn0);
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    return;
+  }
   for (int id = wg; id < ntiles; id += G) {
     int tm, tn;
     tile_of(id, tm, tn);
@@ -960,7 +1052,7 @@ double s256_best_cost(int epi, int M, int N, int* cus_out) {
 #define DARK_S256_LAUNCH_T(E, PB, MI_, TU, BIAS_PTR, MDEV, C2, RANGE)                                                 \
   {                                                                                                                   \
     const int tilesM = cdiv(M, 32 * MI_), ntiles = tilesM * tilesN, grid = min(ntiles, cus);                          \
-    const int smem = s_smem(E, MI_) + (E == EPI_BIAS ? tilesN * 256 * 4 : 0);                                         \
+    const int smem = s_smem(E, MI_) + (E == EPI_BIAS ? tilesN * 256 * 4 : 0) + (((TU) & 64) ? 64 : 0);                \
     static SmemOptIn optin;                                                                                           \
     DARK_TRY(optin.ensure((const void*)gemm_bf16_s256<E, PB, MI_, TU>, smem, st));                                    \
     hipLaunchKernelGGL((gemm_bf16_s256<E, PB, MI_, TU>), dim3(grid), dim3(512), smem, st, (const bf16_t*)A,           \
@@ -1029,6 +1121,7 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
     else if (tune == 9) { DARK_S256_TUNED(9) }
     else if (tune == 5 + (5 << 4)) { DARK_S256_TUNED(85) }
     else if (tune == 5 + (7 << 4)) { DARK_S256_TUNED(117) }
+    else if (tune == 64) { DARK_S256_TUNED(64) }
     else { set_error("gemm_s256: TUNE %d is not instantiated", tune); return DARK_ERR_ARG; }
 #undef DARK_S256_TUNED
   }
