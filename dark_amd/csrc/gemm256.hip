@@ -884,13 +884,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
       const long long t3 = now();
       // ================= MFMA interval =================
       if constexpr (PROBE & 128) {  // timing probe: data movement only (one MFMA keeps the fragments alive)
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kt & 3], fa[kt & 7], kt ? acc[0][0] : (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // (the fragments are kept alive by empty asm operands: a run-time register index would send them to scratch)
+#pragma unroll
+        for (int j = 0; j < P_NI; ++j) asm volatile("" ::"v"(fw[j]));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(fa[i]));
         if (kt == 0) {
 #pragma unroll
           for (int j = 0; j < P_NI; ++j)
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-              if (i + j) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < MI; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       } else if (kt == 0) {
 #pragma unroll
