@@ -26,6 +26,7 @@
 // descriptor's bounds check (row offsets travel in the VGPR operand, the only one the check covers), so edge tiles
 // need no clamping.
 #include "common.h"
+#include <type_traits>
 
 namespace dark {
 
@@ -389,15 +390,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   constexpr int OPS_A = (TUNE & 4) ? C0 : OPSHI, OPS_B = (TUNE & 4) ? B1 + 1 : OPSLO, OPS_C = (TUNE & 4) ? B1 : OPSLO;
   const int ops_class = (TUNE & 4) ? (wave < 4 ? 0 : ((wave - 4) < X1 ? 1 : 2)) : ((NHI > 0 && hi) ? 0 : 1);
   // wait until at most (ops per K-tile) * (NB - 2) [+ NST behind an epilogue] vector-memory operations are outstanding
-  auto wait_batches = [&](bool with_stores, bool lgkm0) {
+  // (TUNE bit 5: at the waits inside the loop the newest batch is one piece short -- that piece follows the MFMAs)
+  auto wait_batches_d = [&](bool with_stores, bool lgkm0, auto defer_c) {
+    constexpr int defer = decltype(defer_c)::value;
 #define DARK_WB(OPS_)                                                                                     \
     {                                                                                                     \
       if (with_stores) {                                                                                  \
-        if (lgkm0) __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2) + NST) & 0xF0FF);              \
-        else __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2) + NST));                             \
+        if (lgkm0) __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2) + NST - defer) & 0xF0FF);      \
+        else __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2) + NST - defer));                     \
       } else {                                                                                            \
-        if (lgkm0) __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2)) & 0xF0FF);                    \
-        else __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2)));                                   \
+        if (lgkm0) __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2) - defer) & 0xF0FF);            \
+        else __builtin_amdgcn_s_waitcnt(waitcnt_vm((OPS_) * (NB - 2) - defer));                           \
       }                                                                                                   \
     }
     if (ops_class == 0) DARK_WB(OPS_A)
@@ -405,6 +408,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
     else DARK_WB(OPS_C)
 #undef DARK_WB
   };
+  auto wait_batches = [&](bool with_stores, bool lgkm0) { wait_batches_d(with_stores, lgkm0, std::integral_constant<int, 0>{}); };
   auto stage = [&](int buf, unsigned a0, unsigned w0, int kt) {
     char* base = smem + buf * S_BUF;
     if constexpr (TUNE & 4) {
@@ -723,6 +727,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
 
   int pm0 = 0, pn0 = 0;   // the tile whose accumulators are waiting for their epilogue
   bool pending = false;
+  // (TUNE bit 5) the deferred piece of this wave's batch: its last one (the extra A piece of a hi wave, else the second W piece)
+  const int def_q = (NHI > 0 && hi) ? NALO + 2 : NALO + 1;
+  unsigned def_a0 = 0, def_w0 = 0;
+  int def_kt = 0, def_buf = 0;
   long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto now = [&]() -> long long {
     if constexpr (PROBE & 8) return (long long)__builtin_readcyclecounter();
@@ -843,6 +851,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         }
         dma_advance();
         t0a = t0b = now();
+      } else if constexpr (TUNE & 32) {
+        // one DMA piece of this wave's batch is issued behind its MFMAs instead of here: the LOAD interval (reads, then
+        // DMA issue at the TA's 64 B per clock, then the landing wait) is the longer of the two, the MFMA interval has
+        // the slack of one piece
+        const char* as = smem + rbuf * S_BUF + a_rd;
+        const char* ws = smem + rbuf * S_BUF + w_rd;
+#pragma unroll
+        for (int j = 0; j < P_NI; ++j) fw[j] = *(const bf16x8*)(ws + j * 1024);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(as + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        t0a = now();
+        const bool live = d_id < ntiles;
+        def_a0 = live ? d_a0 : 0xF0000000u;
+        def_w0 = live ? d_w0 : 0xF0000000u;
+        def_kt = live ? d_kt : 0;
+        def_buf = d_buf;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (q != def_q) stage_piece(q, def_buf, def_a0, def_w0, def_kt);
+        dma_advance();
+        __builtin_amdgcn_sched_barrier(0);
+        t0b = now();
       } else {
       if (!(PROBE & 2) || (!pending && kt == 0)) {
         const char* as = smem + rbuf * S_BUF + a_rd;
@@ -867,7 +898,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         t1 = now();
       }
       const bool behind_epi = pending && kt < NB - 2;
-      if constexpr (TUNE != 0) {
+      if constexpr (TUNE & 32) {
+        wait_batches_d(behind_epi, true, std::integral_constant<int, 1>{});
+      } else if constexpr (TUNE != 0) {
         if ((TUNE & 1) && grp == 0) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); the DMA wait follows the MFMAs
         else wait_batches(behind_epi, true);
       } else if (NHI == 0 || !hi) {
@@ -908,6 +941,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
           for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (TUNE & 32) {
+        stage_piece(def_q, def_buf, def_a0, def_w0, def_kt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       const long long t4 = now();
       if constexpr (TUNE & 1) {
         // group 0's pieces of K-tile kt + 1: first read (by group 0 itself) behind the barrier below, which group 1
@@ -1125,6 +1162,7 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
     else if (tune == 5 + (5 << 4)) { DARK_S256_TUNED(85) }
     else if (tune == 5 + (7 << 4)) { DARK_S256_TUNED(117) }
     else if (tune == 64) { DARK_S256_TUNED(64) }
+    else if (tune == 32) { DARK_S256_TUNED(32) }
     else { set_error("gemm_s256: TUNE %d is not instantiated", tune); return DARK_ERR_ARG; }
 #undef DARK_S256_TUNED
   }
