@@ -678,13 +678,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
           ik = gt ? k : ik;
         }
         int col = (ik >> 2) * 16 + 4 * fq + (ik & 3);
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-          const float om = __shfl_xor(mxl, o, 64);
-          const int oc = __shfl_xor(col, o, 64);
-          const bool take = om > mxl || (om == mxl && oc < col);
-          mxl = take ? om : mxl;
-          col = take ? oc : col;
+        // the four lanes of a row (l, l + 16, l + 32, l + 48) are combined with the row-swap instructions instead of
+        // xor-shuffles through LDS: a swap of x with itself hands every lane BOTH values of its pair (even row's, odd
+        // row's), so the pair's result is formed identically in both lanes -- the same values as the shuffle form,
+        // which combined own and partner symmetrically -- without an LDS round trip and its wait
+        {
+          const auto pm = __builtin_amdgcn_permlane16_swap(__float_as_uint(mxl), __float_as_uint(mxl), false, false);
+          const auto pc = __builtin_amdgcn_permlane16_swap((unsigned)col, (unsigned)col, false, false);
+          const float m0 = __uint_as_float(pm[0]), m1 = __uint_as_float(pm[1]);
+          const int c0 = (int)pc[0], c1 = (int)pc[1];
+          const bool take = m1 > m0 || (m1 == m0 && c1 < c0);
+          mxl = take ? m1 : m0;
+          col = take ? c1 : c0;
+        }
+        {
+          const auto pm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxl), __float_as_uint(mxl), false, false);
+          const auto pc = __builtin_amdgcn_permlane32_swap((unsigned)col, (unsigned)col, false, false);
+          const float m0 = __uint_as_float(pm[0]), m1 = __uint_as_float(pm[1]);
+          const int c0 = (int)pc[0], c1 = (int)pc[1];
+          const bool take = m1 > m0 || (m1 == m0 && c1 < c0);
+          mxl = take ? m1 : m0;
+          col = take ? c1 : c0;
         }
         const bool any = mxl > -INFINITY;
         const float thr = mxl - (hp_range + 2e-6f * fabsf(mxl));  // (the slack covers the roundings of l / T, see sample.hip)
@@ -695,10 +709,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
           sum += __builtin_amdgcn_exp2f((l[k] - mxl) * hp_c2);  // (-inf - finite) * c2 = -inf -> 0
           nn += l[k] > thr ? 1 : 0;
         }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        nn += __shfl_xor(nn, 16, 64);
-        nn += __shfl_xor(nn, 32, 64);
+        {
+          const auto ps = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+          const auto pn = __builtin_amdgcn_permlane16_swap((unsigned)nn, (unsigned)nn, false, false);
+          sum = __uint_as_float(ps[0]) + __uint_as_float(ps[1]);
+          nn = (int)(pn[0] + pn[1]);
+        }
+        {
+          const auto ps = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+          const auto pn = __builtin_amdgcn_permlane32_swap((unsigned)nn, (unsigned)nn, false, false);
+          sum = __uint_as_float(ps[0]) + __uint_as_float(ps[1]);
+          nn = (int)(pn[0] + pn[1]);
+        }
         const float tsum = any ? sum - 1.0f : 0.f;
         const int P = tilesN * 4;
         const unsigned off = (m < M && fq == 0 && nb < N) ? (unsigned)(((int64_t)m * P + (nb >> 6)) * 16) : 0xF0000000u;
