@@ -499,8 +499,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
   {
     int tm, tn;
     tile_of(d_id, tm, tn);
-    d_a0 = (unsigned)tm * (unsigned)TM * kb;
-    d_w0 = (unsigned)tn * 256u * kb;
+    // (PROBE bit 5, timing only, WRONG results: every tile streams the SAME row panel and column tile, so that every DMA
+    // hits in the XCD's L2: what the launch costs when no piece waits for the Infinity Cache)
+    d_a0 = (PROBE & 32) ? 0u : (unsigned)tm * (unsigned)TM * kb;
+    d_w0 = (PROBE & 32) ? 0u : (unsigned)tn * 256u * kb;
   }
   bool probe_warm = false;  // (PROBE builds: set once the pipeline is primed)
   auto dma_advance = [&]() {
@@ -511,8 +513,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
       if (d_id < ntiles) {
         int tm, tn;
         tile_of(d_id, tm, tn);
-        d_a0 = (unsigned)tm * (unsigned)TM * kb;
-        d_w0 = (unsigned)tn * 256u * kb;
+        d_a0 = (PROBE & 32) ? 0u : (unsigned)tm * (unsigned)TM * kb;
+        d_w0 = (PROBE & 32) ? 0u : (unsigned)tn * 256u * kb;
       }
     }
   };
@@ -529,8 +531,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
       if (d_id < ntiles) {
         int tm, tn;
         tile_of(d_id, tm, tn);
-        d_a0 = (unsigned)tm * (unsigned)TM * kb;
-        d_w0 = (unsigned)tn * 256u * kb;
+        d_a0 = (PROBE & 32) ? 0u : (unsigned)tm * (unsigned)TM * kb;
+        d_w0 = (PROBE & 32) ? 0u : (unsigned)tn * 256u * kb;
       }
     }
   };
@@ -1160,6 +1162,8 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   else if (probe == 144) DARK_S256_LAUNCH(EPI_SWIGLU, 144, 8, bias, no_mdev, 0.f, 0.f)
   else if (probe == 148) DARK_S256_LAUNCH(EPI_SWIGLU, 148, 8, bias, no_mdev, 0.f, 0.f)
   else if (probe == 9) DARK_S256_LAUNCH(EPI_SWIGLU, 8, 10, bias, no_mdev, 0.f, 0.f)   // (per-phase sums of the 320-row tile)
+  else if (probe == 32) DARK_S256_LAUNCH(EPI_SWIGLU, 32, 10, bias, no_mdev, 0.f, 0.f)  // (every DMA an L2 hit, 320-row tile)
+  else if (probe == 40) DARK_S256_LAUNCH(EPI_SWIGLU, 40, 10, bias, no_mdev, 0.f, 0.f)  // (the same with per-phase sums)
   else if (probe == 24 + 64) DARK_S256_LAUNCH_T(EPI_SWIGLU, 8, 10, 1, bias, no_mdev, 0.f, 0.f)   // (per-phase sums, TUNE 1)
   else if (probe == 24 + 65) DARK_S256_LAUNCH_T(EPI_SWIGLU, 8, 10, 5, bias, no_mdev, 0.f, 0.f)   // (per-phase sums, TUNE 5)
   else if (probe == 24 + 66) DARK_S256_LAUNCH_T(EPI_SWIGLU, 8, 10, 8, bias, no_mdev, 0.f, 0.f)   // (per-phase sums, TUNE 8)
