@@ -529,6 +529,40 @@ def test_two_stage_sampler_equals_single_stage_bit_for_bit(lib, V, ld_pad):
         H.check(lib.dark_dbg_set_sampler_stages(0))
 
 
+@pytest.mark.parametrize("V", [25427, 15081])
+def test_sampler_unpadded_stride_equals_padded_two_stage(lib, V):
+    """A caller that hands over logits on a stride of V with V % 4 != 0 (sample_into, the expand loop) is served by the
+    single-stage kernel's scalar row load; head_and_sample pads the stride and takes the two stages.  Same rows, same
+    noise: conf and x0 bit for bit (the dispatch depends on ldl % 4 and the base alignment)."""
+    H = _hip()
+    g = torch.Generator().manual_seed(5 + V)
+    M = 200
+    rows = torch.randn(M, V, generator=g) * torch.tensor([0.3, 1.0, 6.0, 25.0])[torch.arange(M) % 4][:, None]
+    rows[3, 7:60] = rows[3].max() + 0.5
+    rows[4, V - 2:] = rows[4].max() + 3.0
+    noise = torch.empty(M, V).exponential_(1, generator=g).to(DEV)
+    ldp = (V + 3) & ~3
+    padded = torch.zeros(M, ldp)
+    padded[:, :V] = rows
+    padded = padded.to(DEV)
+    plain = rows.to(DEV).contiguous()
+    assert plain.stride(0) % 4 != 0
+    out = {}
+    for name, lg, ld in (("plain", plain, V), ("padded", padded, ldp)):
+        for T, top_p, mode in ((0.1, 0.9, 2), (0.5, 0.9, 0), (1.0, 0.95, 1), (0.0, 0.9, 2)):
+            conf = torch.full((M,), -7.0, device=DEV)
+            x0 = torch.full((M,), -7, dtype=torch.long, device=DEV)
+            H.check(lib.dark_sample_rows(H.ptr(lg), ld, M, V, T, top_p, 0, mode, H.ptr(noise) if T > 0 else None,
+                                         V if T > 0 else 0, H.ptr(conf), H.ptr(x0), _s()))
+            torch.cuda.synchronize()
+            out[(name, T, top_p, mode)] = (conf.cpu().view(torch.int32), x0.cpu())
+    for (name, T, top_p, mode), (c, x) in out.items():
+        if name == "plain":
+            cp, xp = out[("padded", T, top_p, mode)]
+            assert torch.equal(x, xp) and torch.equal(c, cp), (T, top_p, mode)
+            assert int(x.min()) >= 0 and int(x.max()) < V
+
+
 def test_sample_rows_kept_set_matches_top_p(lib):
     """Property at full size: with noise concentrated on one token, x0 must be that token iff it survives
     the nucleus filter of the oracle."""
