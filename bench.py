@@ -111,6 +111,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     grouped = world > 1 or args.force_dist
+    # ONE JSON line on stdout and nothing else: RCCL prints a version banner and gloo a connection note on file
+    # descriptor 1 when a communicator comes up; until the result is printed, descriptor 1 points at stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if grouped:
         if args.rehearse:
             dist.init_process_group("gloo")
@@ -263,9 +268,13 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, weights, args, synth)
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if grouped:
+        os.dup2(2, 1)   # (the teardown may talk as well)
         dist.destroy_process_group()
 
 
