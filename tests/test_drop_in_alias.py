@@ -5,6 +5,7 @@ has produced ids -- runs unchanged on it: same imports, same constructor keyword
 (``number_transfer_tokens=1`` included), same use of the result.  The decode step is checked at the id level through
 ``dark_split_strip`` (the strings are the tokenizer's)."""
 import importlib
+import os
 import sys
 
 import pytest
@@ -174,3 +175,31 @@ def test_restated_grpo_rollout_call(akgr_modules):
     assert torch.equal(out[:, :45][keep], prompt_ids[keep])
     groups = out.view(6, 4, 46)
     assert any(not torch.equal(groups[q, 0], groups[q, j]) for q in range(6) for j in range(1, 4))
+
+
+@pytest.mark.gpu
+def test_integration_md_ctypes_stub_runs_and_matches_the_oracle():
+    """The ctypes stub INTEGRATION.md section 2 shows a maintainer (`sample_tokens` over `dark_sample_rows`) is executed
+    as printed -- only the library path is made absolute -- and checked against the oracle's `sample_tokens`
+    (generation_utils.py:58-90) for `top_p=None` and `top_p=0.9` at T = 0 (no draw involved) and T > 0 (finite tokens)."""
+    import re
+    from dark_amd import _hip
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(import ctypes as C, torch\n.*?)```", md, re.S).group(1)
+    assert 'C.CDLL("libdark_hip.so")' in block
+    block = block.replace('C.CDLL("libdark_hip.so")', f"C.CDLL({_hip.LIB_PATH!r})")
+    block = block.replace("lib.dark_hip_last_error().decode()", "str(rc)")   # (restype of the message call is not set in the stub)
+    ns = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn(64, 512, generator=g) * 3).cuda()
+    for top_p in (None, 0.9):
+        conf, x0 = ns["sample_tokens"](logits, temperature=0.0, top_p=top_p, neg_entropy=True)
+        oc, ox = O.sample_tokens(logits.cpu(), temperature=0.0, top_p=top_p, neg_entropy=True)
+        torch.cuda.synchronize()
+        assert torch.equal(x0.cpu(), ox), top_p
+        assert torch.allclose(conf.cpu(), oc, rtol=1e-4, atol=1e-6), top_p
+        conf, x0 = ns["sample_tokens"](logits, temperature=0.7, top_p=top_p)
+        torch.cuda.synchronize()
+        assert int(x0.min()) >= 0 and int(x0.max()) < 512 and bool(torch.isfinite(conf).all())
