@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--materialise-noise", action="store_true",
                     help="fill the [M,V] categorical noise with torch instead of computing it in the sampler")
     ap.add_argument("--cpu-sample", type=int, default=48, help="sequences in the CPU-oracle sample")
-    ap.add_argument("--gemm-variant", type=int, default=0, choices=[0, 1, 2, 4, 5, 6, 7, 11, 12, 13] + list(range(1000, 1128)),
+    ap.add_argument("--gemm-variant", type=int, default=0, choices=[0, 1, 2, 4, 5, 6, 7, 11, 12, 13, 14] + list(range(1000, 1128)),
                     help="A/B hook: 0 = the library's choice, 1 = 128-row GEMM kernels only, 2 / 4 = the persistent 256x256 "
                          "kernel (plain / staggered) wherever it supports the shape; 6 / 7 / 11 = the library's choice "
                          "without the down_proj routing / without the q/k/v routing / with o_proj on the persistent kernel")

@@ -527,7 +527,7 @@ int dark_prof_read(double* total_ms, double* total_flops, int* launches) {
 }
 
 int dark_dbg_set_gemm_variant(int variant) {
-  DARK_CHECK_ARG((variant >= 0 && variant <= 13) || (variant >= 16 && variant <= 16 + 255) || (variant >= 1000 && variant < 1128),
+  DARK_CHECK_ARG((variant >= 0 && variant <= 14) || (variant >= 16 && variant <= 16 + 255) || (variant >= 1000 && variant < 1128),
                  "set_gemm_variant: %d", variant);
   set_gemm_variant(variant);
   return DARK_OK;

@@ -704,8 +704,10 @@ double s256_best_cost(int epi, int M, int N, int* cus_out);
 // 1000 + t = the automatic choice with gemm_bf16_s256's TUNE = t wherever that kernel runs (results unchanged)
 void set_s256_tune(int v);
 void set_attn_variant(int v);   // (attn.hip; 12 = the library's GEMM choice + the attention kernel's A/B form)
+void set_s256_interleave(int v);   // (gemm256.hip; 14 = the library's choice without the interleaved LOAD interval)
 void set_gemm_variant(int v) {
   set_attn_variant(v == 12 ? 1 : 0);
+  set_s256_interleave(v == 14 ? 0 : 1);
   const bool tuned = v >= 1000;
   set_s256_tune(tuned ? v - 1000 : 0);
   if (tuned) v = 0;
@@ -728,7 +730,7 @@ static int pick_kernel(int dtype, int epi, int M, int N, int K, int64_t ldo, con
   // 6 / 7 / 11 = A/B of the automatic choice itself: 6 = without the one-round down_proj routing below, 7 = without
   // q/k/v on the 288-row persistent kernel, 11 = with o_proj there too
   const bool no_resid_s256 = v == 6, qkv_s256 = v != 7, oproj_s256 = v == 11;
-  if (v == 5 || v == 6 || v == 7 || v == 11 || v == 12 || v == 13) v = 0;  // 5 / 13 = automatic GEMM choice + the row-panel kernel for o_proj + down_proj / o_proj only (api.hip); 12 = attention A/B
+  if (v == 5 || v == 6 || v == 7 || v == 11 || v == 12 || v == 13 || v == 14) v = 0;  // 5 / 13 = automatic GEMM choice + the row-panel kernel for o_proj + down_proj / o_proj only (api.hip); 12 = attention A/B
   if (v == 1) return 0;
   const bool p_ok = p256_supports(epi, M, N, K, ldo, out, bias), s_ok = s256_supports(epi, M, N, K, ldo, out, bias);
   if (v == 2) return p_ok ? 2 : 0;

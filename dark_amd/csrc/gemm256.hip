@@ -1066,6 +1066,8 @@ static std::atomic<int> g_s256_probe{0};
 void set_s256_probe(int v) { g_s256_probe.store(v); }
 static std::atomic<int> g_s256_rows{0};   // 0 = automatic, 256 / 288 / 320 = forced tile height (A/B hook)
 void set_s256_rows(int v) { g_s256_rows.store(v); }
+static std::atomic<int> g_s256_interleave{1};   // interleaved LOAD interval for the bias / residual flavours (variant 14 = off)
+void set_s256_interleave(int v) { g_s256_interleave.store(v); }
 static std::atomic<int> g_s256_tune{0};   // TUNE of gemm_bf16_s256 (A/B hook; the instantiated values only)
 void set_s256_tune(int v) { g_s256_tune.store(v); }
 
@@ -1167,7 +1169,8 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   else if (probe == 24 + 64) DARK_S256_LAUNCH_T(EPI_SWIGLU, 8, 10, 1, bias, no_mdev, 0.f, 0.f)   // (per-phase sums, TUNE 1)
   else if (probe == 24 + 65) DARK_S256_LAUNCH_T(EPI_SWIGLU, 8, 10, 5, bias, no_mdev, 0.f, 0.f)   // (per-phase sums, TUNE 5)
   else if (probe == 24 + 66) DARK_S256_LAUNCH_T(EPI_SWIGLU, 8, 10, 8, bias, no_mdev, 0.f, 0.f)   // (per-phase sums, TUNE 8)
-  else if (tune != 0 && mi >= 9 && (epi == EPI_SWIGLU || epi == EPI_BIAS || epi == EPI_RESID_H)) {
+  // (tune 16: TUNE 8 for the bias and residual flavours only -- the SwiGLU flavour is slower with it)
+  else if (tune != 0 && !(tune == 16 && epi == EPI_SWIGLU) && mi >= 9 && (epi == EPI_SWIGLU || epi == EPI_BIAS || epi == EPI_RESID_H)) {
 #define DARK_S256_TUNED(TU)                                                                     \
     if (epi == EPI_SWIGLU) {                                                                    \
       if (mi == 10) DARK_S256_LAUNCH_T(EPI_SWIGLU, 0, 10, TU, bias, no_mdev, 0.f, 0.f)          \
@@ -1183,7 +1186,7 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
     else if (tune == 2) { DARK_S256_TUNED(2) }
     else if (tune == 5) { DARK_S256_TUNED(5) }
     else if (tune == 4) { DARK_S256_TUNED(4) }
-    else if (tune == 8) { DARK_S256_TUNED(8) }
+    else if (tune == 8 || tune == 16) { DARK_S256_TUNED(8) }
     else if (tune == 9) { DARK_S256_TUNED(9) }
     else if (tune == 5 + (5 << 4)) { DARK_S256_TUNED(85) }
     else if (tune == 5 + (7 << 4)) { DARK_S256_TUNED(117) }
@@ -1194,7 +1197,19 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   }
   else
 #endif
+  // The bias and residual flavours on the taller tiles run the LOAD interval with fragment reads and DMA pieces issued
+  // alternately (TUNE 8: the LDS and the texture addresser work at the same time): q/k/v -3 %, down_proj -1.6 % at
+  // kernel level, +0.55 % in the loop in three alternating pairs, the same bits (profiles/r03zf_*); the SwiGLU flavour
+  // is 3 % SLOWER with it and keeps the sequential form.  dark_dbg_set_gemm_variant(14) switches it off.
+  const bool interleave = g_s256_interleave.load(std::memory_order_relaxed) && mi >= 9;
   if (epi == EPI_SWIGLU) { DARK_S256_EITHER(EPI_SWIGLU, no_mdev, 0.f, 0.f) }
+  else if (epi == EPI_BIAS && interleave) {
+    if (mi == 10) DARK_S256_LAUNCH_T(EPI_BIAS, 0, 10, 8, bias, no_mdev, 0.f, 0.f)
+    else DARK_S256_LAUNCH_T(EPI_BIAS, 0, 9, 8, bias, no_mdev, 0.f, 0.f)
+  } else if (epi == EPI_RESID_H && interleave) {
+    if (mi == 10) DARK_S256_LAUNCH_T(EPI_RESID_H, 0, 10, 8, bias, no_mdev, 0.f, 0.f)
+    else DARK_S256_LAUNCH_T(EPI_RESID_H, 0, 9, 8, bias, no_mdev, 0.f, 0.f)
+  }
   else if (epi == EPI_BIAS) { DARK_S256_EITHER(EPI_BIAS, no_mdev, 0.f, 0.f) }
   else if (epi == EPI_RESID_H) { DARK_S256_EITHER(EPI_RESID_H, no_mdev, 0.f, 0.f) }
   else { DARK_S256_EITHER(EPI_F32, no_mdev, 0.f, 0.f) }

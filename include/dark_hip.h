@@ -476,6 +476,8 @@ int dark_dbg_gemm_resid_norm_h(const void* A, const void* W, void* hidden, const
  *   kernel / with o_proj there too (the in-loop A/Bs recorded in DESIGN.md);
  *   12 = the library's GEMM choice with the N <= 128 attention instance's staging loads issued per loop iteration
  *   instead of all up front (the round-2 form; results equal up to the contraction of one multiply-add in the rotation);
+ *   14 = the library's choice with the bias / residual flavours of gemm_bf16_s256 on the sequential LOAD interval
+ *   (fragment reads, then DMA issue) instead of the interleaved one; results unchanged;
  * PROBE BUILD ONLY (libdark_hip_probes.so: `make -C dark_amd/csrc probes`, -DDARK_PROBES; the shipped libdark_hip.so
  * holds no instantiation that gives wrong results and answers DARK_ERR_UNSUPPORTED at the launch):
  *   3 = timing probe of variant 2 (WRONG results); 16 + p = timing probe p of gemm_bf16_s256 (WRONG results unless
