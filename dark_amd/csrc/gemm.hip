@@ -728,8 +728,8 @@ static int pick_kernel(int dtype, int epi, int M, int N, int K, int64_t ldo, con
   if (dtype != DARK_BF16) return 0;
   int v = g_gemm_variant.load(std::memory_order_relaxed);
   // 6 / 7 / 11 = A/B of the automatic choice itself: 6 = without the one-round down_proj routing below, 7 = without
-  // q/k/v on the 288-row persistent kernel, 11 = with o_proj there too
-  const bool no_resid_s256 = v == 6, qkv_s256 = v != 7, oproj_s256 = v == 11;
+  // q/k/v on the 288-row persistent kernel, 11 = without o_proj there
+  const bool no_resid_s256 = v == 6, qkv_s256 = v != 7, oproj_s256 = v != 11;
   if (v == 5 || v == 6 || v == 7 || v == 11 || v == 12 || v == 13 || v == 14) v = 0;  // 5 / 13 = automatic GEMM choice + the row-panel kernel for o_proj + down_proj / o_proj only (api.hip); 12 = attention A/B
   if (v == 1) return 0;
   const bool p_ok = p256_supports(epi, M, N, K, ldo, out, bias), s_ok = s256_supports(epi, M, N, K, ldo, out, bias);
@@ -742,7 +742,8 @@ static int pick_kernel(int dtype, int epi, int M, int N, int K, int64_t ldo, con
   // 256 columns per CU (a round of the 128-row kernel = two 128 x 192 tiles per CU); the 128-row kernel's partial
   // rounds run faster than the model says (a lone workgroup has the CU to itself), hence the 10 % margin.  Measured
   // (tools/gemm_ab.py, M = 23552): 110 -> 88 us.  At K = 768 the one-round launch has no next tile to hide its
-  // prologue and epilogue behind and gains nothing (o_proj stays here).  q/k/v + bias (N = 2304): 738 tiles of 288 x 256
+  // prologue and epilogue behind: 36.5 vs 37.8 us and +-0 in the loop in round 2; with the interleaved LOAD interval of
+  // round 3 +0.2 % in the loop in three alternating pairs (profiles/r03zh_*), so o_proj goes there too.  q/k/v + bias (N = 2304): 738 tiles of 288 x 256
   // are three 96 %-full rounds against 4.3 rounds of 128 x 192: 85.2 vs 89.0 us, +0.2 % in the loop in three
   // alternating pairs (profiles/r02ab_qkv_routing_ab.txt) -- small, but the same bits from one kernel family.
   if (s_ok && ((epi == EPI_RESID_H && (K >= 1536 || oproj_s256) && !no_resid_s256) || (epi == EPI_BIAS && qkv_s256))) {

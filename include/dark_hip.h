@@ -473,7 +473,7 @@ int dark_dbg_gemm_resid_norm_h(const void* A, const void* W, void* hidden, const
  *   5 = the library's choice + the row-panel kernel for both residual projections (either stream dtype);
  *   13 = the library's choice + the row-panel kernel for o_proj only (bf16 residual stream);
  *   6 / 7 / 11 = the library's choice without its one-round down_proj routing / without q/k/v on the persistent
- *   kernel / with o_proj there too (the in-loop A/Bs recorded in DESIGN.md);
+ *   kernel / without o_proj there (the in-loop A/Bs recorded in DESIGN.md);
  *   12 = the library's GEMM choice with the N <= 128 attention instance's staging loads issued per loop iteration
  *   instead of all up front (the round-2 form; results equal up to the contraction of one multiply-add in the rotation);
  *   14 = the library's choice with the bias / residual flavours of gemm_bf16_s256 on the sequential LOAD interval
