@@ -248,7 +248,7 @@ def main():
         "forward_mfma_frac": round(alg_flops * args.steps * world / dt / 1e12 / (peak * world), 4),
         # ... and the FLOPs this build executes (last layer's o_proj / MLP on the masked rows only)
         "forward_mfma_frac_executed": round(exe_flops * args.steps * world / dt / 1e12 / (peak * world), 4),
-        "roofline": {"bound": "mfma", "kernel": (({0: "gemm_bf16_s256<2, 0, 10>", 4: "gemm_bf16_s256<2, 0, 10>", 2: "gemm_bf16_p256<2, false>"}.get(
+        "roofline": {"bound": "mfma", "kernel": (({0: "gemm_bf16_s256<2, 0, 10, 10>", 14: "gemm_bf16_s256<2, 0, 10, 0>", 4: "gemm_bf16_s256<2, 0, 10, 10>", 2: "gemm_bf16_p256<2, false>"}.get(
                                     args.gemm_variant, "gemm_bf16_kernel16<2, 192>") if args.dtype == "bf16" else "gemm_f32_kernel<2>")
                                 + f" = EPI_SWIGLU (gate/up projection + SiLU*up, the {rows_full}-row launches of layers 0..L-2, "
                                   "N=6144, K=768)"),

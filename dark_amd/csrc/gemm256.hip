@@ -848,7 +848,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
     for (int kt = 0; kt < KT; ++kt) {
       // ================= LOAD interval =================
       const long long t0 = now();
-      if constexpr (TUNE & 2) __builtin_amdgcn_s_setprio(1);
+      if constexpr ((TUNE & 2) && !(TUNE & 8)) __builtin_amdgcn_s_setprio(1);
       if (kt == 0 && pending) epilogue(pm0, pn0);   // the partner group's MFMAs run meanwhile
       const long long t0e = now();
       long long t0a = 0, t0b = 0;
@@ -862,6 +862,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         const unsigned ca0 = live ? d_a0 : 0xF0000000u, cw0 = live ? d_w0 : 0xF0000000u;
         const int ckt = live ? d_kt : 0;
         constexpr int NR = P_NI + MI;
+        if ((TUNE & 2) && kt == 0 && pending) {
+          // (TUNE 10: behind an epilogue the sequential form -- the reads first, while the epilogue's stores drain)
+#pragma unroll
+          for (int j = 0; j < P_NI; ++j) fw[j] = *(const bf16x8*)(ws + j * 1024);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(as + i * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) stage_piece(q, d_buf, ca0, cw0, ckt);
+          __builtin_amdgcn_sched_barrier(0);
+        } else
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
 #pragma unroll
@@ -935,7 +946,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         else __builtin_amdgcn_s_waitcnt(waitcnt_vm(OPSHI * (NB - 2)) & 0xF0FF);
       }
       if constexpr (PROBE & 8) t2 = now();
-      if constexpr (TUNE & 2) __builtin_amdgcn_s_setprio(0);
+      if constexpr ((TUNE & 2) && !(TUNE & 8)) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       const long long t3 = now();
@@ -1144,6 +1155,7 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   const int probe = epi == EPI_SWIGLU ? g_s256_probe.load() : 0;   // timing probes: gate/up flavour, 256-row tile
   const int tune = g_s256_tune.load(std::memory_order_relaxed);
   const int* no_mdev = nullptr;
+  const bool interleave = g_s256_interleave.load(std::memory_order_relaxed) && mi >= 9;   // (see the product launches below)
 #ifndef DARK_PROBES
   // the shipped library holds the product instantiations only; timing probes (some give WRONG results) and the TUNE
   // A/B forms exist in the probe build (make probes -> libdark_hip_probes.so, loaded by tools/ when DARK_HIP_LIB names it)
@@ -1187,6 +1199,7 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
     else if (tune == 5) { DARK_S256_TUNED(5) }
     else if (tune == 4) { DARK_S256_TUNED(4) }
     else if (tune == 8 || tune == 16) { DARK_S256_TUNED(8) }
+    else if (tune == 10) { DARK_S256_TUNED(10) }
     else if (tune == 9) { DARK_S256_TUNED(9) }
     else if (tune == 5 + (5 << 4)) { DARK_S256_TUNED(85) }
     else if (tune == 5 + (7 << 4)) { DARK_S256_TUNED(117) }
@@ -1197,18 +1210,21 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
   }
   else
 #endif
-  // The bias and residual flavours on the taller tiles run the LOAD interval with fragment reads and DMA pieces issued
-  // alternately (TUNE 8: the LDS and the texture addresser work at the same time): q/k/v -3 %, down_proj -1.6 % at
-  // kernel level, +0.55 % in the loop in three alternating pairs, the same bits (profiles/r03zf_*); the SwiGLU flavour
-  // is 3 % SLOWER with it and keeps the sequential form.  dark_dbg_set_gemm_variant(14) switches it off.
-  const bool interleave = g_s256_interleave.load(std::memory_order_relaxed) && mi >= 9;
-  if (epi == EPI_SWIGLU) { DARK_S256_EITHER(EPI_SWIGLU, no_mdev, 0.f, 0.f) }
+  // On the taller tiles the LOAD interval issues fragment reads and DMA pieces alternately (the LDS and the texture
+  // addresser work at the same time), except behind an epilogue, where the reads go first while the epilogue's stores
+  // drain (TUNE 10).  Bit-identical; in the loop +0.5 % for the bias and residual flavours (profiles/r03zf_*) and a
+  // further +0.3 % with the SwiGLU flavour included (r03zk_*), each in three alternating pairs; dominant launch -1 %.
+  // dark_dbg_set_gemm_variant(14) switches it off.
+  if (interleave && epi == EPI_SWIGLU) {
+    if (mi == 10) DARK_S256_LAUNCH_T(EPI_SWIGLU, 0, 10, 10, bias, no_mdev, 0.f, 0.f)
+    else DARK_S256_LAUNCH_T(EPI_SWIGLU, 0, 9, 10, bias, no_mdev, 0.f, 0.f)
+  } else if (epi == EPI_SWIGLU) { DARK_S256_EITHER(EPI_SWIGLU, no_mdev, 0.f, 0.f) }
   else if (epi == EPI_BIAS && interleave) {
-    if (mi == 10) DARK_S256_LAUNCH_T(EPI_BIAS, 0, 10, 8, bias, no_mdev, 0.f, 0.f)
-    else DARK_S256_LAUNCH_T(EPI_BIAS, 0, 9, 8, bias, no_mdev, 0.f, 0.f)
+    if (mi == 10) DARK_S256_LAUNCH_T(EPI_BIAS, 0, 10, 10, bias, no_mdev, 0.f, 0.f)
+    else DARK_S256_LAUNCH_T(EPI_BIAS, 0, 9, 10, bias, no_mdev, 0.f, 0.f)
   } else if (epi == EPI_RESID_H && interleave) {
-    if (mi == 10) DARK_S256_LAUNCH_T(EPI_RESID_H, 0, 10, 8, bias, no_mdev, 0.f, 0.f)
-    else DARK_S256_LAUNCH_T(EPI_RESID_H, 0, 9, 8, bias, no_mdev, 0.f, 0.f)
+    if (mi == 10) DARK_S256_LAUNCH_T(EPI_RESID_H, 0, 10, 10, bias, no_mdev, 0.f, 0.f)
+    else DARK_S256_LAUNCH_T(EPI_RESID_H, 0, 9, 10, bias, no_mdev, 0.f, 0.f)
   }
   else if (epi == EPI_BIAS) { DARK_S256_EITHER(EPI_BIAS, no_mdev, 0.f, 0.f) }
   else if (epi == EPI_RESID_H) { DARK_S256_EITHER(EPI_RESID_H, no_mdev, 0.f, 0.f) }

@@ -37,10 +37,10 @@ txt = open(sys.argv[1]).read()
 vals = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     sec = txt.split("# ---- pass " + counter)[1].split("# ---- pass")[0]
-    m = re.search(r"gemm_bf16_s256<2, 0, 10(?:, 0)?>.*?\n\s+dispatches.*?\n\s+" + counter + r"\s+(\d+)", sec, re.S)
+    m = re.search(r"gemm_bf16_s256<2, 0, 10(?:, \d+)?>.*?\n\s+dispatches.*?\n\s+" + counter + r"\s+(\d+)", sec, re.S)
     vals[counter] = int(m.group(1))
 kib = 2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]   # FETCH_SIZE reads half the bytes of wide streaming reads on gfx950
-json.dump({"kernel": "gemm_bf16_s256<2, 0, 10>", "dtype": "bf16", "batch": 1024, "fetch_size_kib": vals["FETCH_SIZE"],
+json.dump({"kernel": "gemm_bf16_s256<2, 0, 10, 10>", "dtype": "bf16", "batch": 1024, "fetch_size_kib": vals["FETCH_SIZE"],
            "write_size_kib": vals["WRITE_SIZE"], "traffic_bytes_per_launch": kib * 1024,
            "source": "profiles/%s_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; 2 x FETCH + WRITE)" % sys.argv[3]},
           open(sys.argv[2], "w"), indent=1)
