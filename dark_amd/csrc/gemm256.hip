@@ -849,6 +849,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
       // ================= LOAD interval =================
       const long long t0 = now();
       if constexpr ((TUNE & 2) && !(TUNE & 8)) __builtin_amdgcn_s_setprio(1);
+      bool early_dma = false;
+      if constexpr ((TUNE & 26) == 26) {
+        // (TUNE 26) behind a finished tile the interval's DMA batch goes out BEFORE the epilogue: 1.3 us of epilogue in
+        // front of it would eat most of the batch's two K-tiles of lead
+        if (kt == 0 && pending) {
+          const bool live = d_id < ntiles;
+          const unsigned ca0 = live ? d_a0 : 0xF0000000u, cw0 = live ? d_w0 : 0xF0000000u;
+          const int ckt = live ? d_kt : 0;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) stage_piece(q, d_buf, ca0, cw0, ckt);
+          dma_advance();
+          __builtin_amdgcn_sched_barrier(0);
+          early_dma = true;
+        }
+      }
       if (kt == 0 && pending) epilogue(pm0, pn0);   // the partner group's MFMAs run meanwhile
       const long long t0e = now();
       long long t0a = 0, t0b = 0;
@@ -869,8 +884,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
 #pragma unroll
           for (int i = 0; i < MI; ++i) fa[i] = *(const bf16x8*)(as + i * 1024);
           __builtin_amdgcn_sched_barrier(0);
+          if (!early_dma) {
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) stage_piece(q, d_buf, ca0, cw0, ckt);
+            for (int q = 0; q < NQ; ++q) stage_piece(q, d_buf, ca0, cw0, ckt);
+          }
           __builtin_amdgcn_sched_barrier(0);
         } else
 #pragma unroll
@@ -884,7 +901,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
           else fa[r - P_NI] = *(const bf16x8*)(as + (r - P_NI) * 1024);
           __builtin_amdgcn_sched_barrier(0);
         }
-        dma_advance();
+        if (!early_dma) dma_advance();
         t0a = t0b = now();
       } else if constexpr (TUNE & 32) {
         // one DMA piece of this wave's batch is issued behind its MFMAs instead of here: the LOAD interval (reads, then
@@ -932,7 +949,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: the fragment reads have returned
         t1 = now();
       }
-      const bool behind_epi = pending && kt < NB - 2;
+      const bool behind_epi = pending && kt < (((TUNE & 26) == 26) ? NB - 1 : NB - 2);   // (TUNE 26: the stores follow that interval's batch)
       if constexpr (TUNE & 32) {
         wait_batches_d(behind_epi, true, std::integral_constant<int, 1>{});
       } else if constexpr (TUNE != 0) {
@@ -1200,6 +1217,7 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
     else if (tune == 4) { DARK_S256_TUNED(4) }
     else if (tune == 8 || tune == 16) { DARK_S256_TUNED(8) }
     else if (tune == 10) { DARK_S256_TUNED(10) }
+    else if (tune == 26) { DARK_S256_TUNED(26) }
     else if (tune == 9) { DARK_S256_TUNED(9) }
     else if (tune == 5 + (5 << 4)) { DARK_S256_TUNED(85) }
     else if (tune == 5 + (7 << 4)) { DARK_S256_TUNED(117) }
