@@ -889,6 +889,32 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
             for (int q = 0; q < NQ; ++q) stage_piece(q, d_buf, ca0, cw0, ckt);
           }
           __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr ((TUNE & 42) == 42) {
+          // (TUNE 42) the four waves of a group place their DMA pieces at different reads (piece j in front of read
+          // 3 j + wave % 3), so that they do not all queue at the texture addresser at the same moment; one copy of the
+          // unrolled sequence per offset (a run-time piece index costs far more than it saves: 1.75 x slower)
+          auto il = [&](auto offc) {
+            constexpr int OFF = decltype(offc)::value;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+#pragma unroll
+              for (int q = 0; q < NQ; ++q)
+                if (3 * q + OFF == r) {
+                  stage_piece(q, d_buf, ca0, cw0, ckt);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              if (r < P_NI) fw[r] = *(const bf16x8*)(ws + r * 1024);
+              else fa[r - P_NI] = *(const bf16x8*)(as + (r - P_NI) * 1024);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              if (3 * q + OFF >= NR) stage_piece(q, d_buf, ca0, cw0, ckt);
+          };
+          const int off = wn % 3;
+          if (off == 0) il(std::integral_constant<int, 0>{});
+          else if (off == 1) il(std::integral_constant<int, 1>{});
+          else il(std::integral_constant<int, 2>{});
         } else
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -950,7 +976,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
         t1 = now();
       }
       const bool behind_epi = pending && kt < (((TUNE & 26) == 26) ? NB - 1 : NB - 2);   // (TUNE 26: the stores follow that interval's batch)
-      if constexpr (TUNE & 32) {
+      if constexpr ((TUNE & 32) && !(TUNE & 8)) {
         wait_batches_d(behind_epi, true, std::integral_constant<int, 1>{});
       } else if constexpr (TUNE != 0) {
         if ((TUNE & 1) && grp == 0) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); the DMA wait follows the MFMAs
@@ -993,7 +1019,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_s256(const bf16_t* __restrict__
           for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (TUNE & 32) {
+      if constexpr ((TUNE & 32) && !(TUNE & 8)) {
         stage_piece(def_q, def_buf, def_a0, def_w0, def_kt);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1218,6 +1244,7 @@ int launch_gemm_s256(int epi, const void* A, const void* W, const float* bias, v
     else if (tune == 8 || tune == 16) { DARK_S256_TUNED(8) }
     else if (tune == 10) { DARK_S256_TUNED(10) }
     else if (tune == 26) { DARK_S256_TUNED(26) }
+    else if (tune == 42) { DARK_S256_TUNED(42) }
     else if (tune == 9) { DARK_S256_TUNED(9) }
     else if (tune == 5 + (5 << 4)) { DARK_S256_TUNED(85) }
     else if (tune == 5 + (7 << 4)) { DARK_S256_TUNED(117) }
