@@ -22,8 +22,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", default="1,3h,4,5")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--gemm-variant", type=int, default=0, help="dark_dbg_set_gemm_variant (A/B runs)")
     a = ap.parse_args()
-    from dark_amd import DreamConfig, DreamGenerationConfig, DreamModel_length, synth
+    from dark_amd import DreamConfig, DreamGenerationConfig, DreamModel_length, _hip, synth
+    _hip.check(_hip.load().dark_dbg_set_gemm_variant(a.gemm_variant))
     dev = torch.device("cuda", 0)
     import warnings
     warnings.filterwarnings("ignore", message="Padding was detected")
