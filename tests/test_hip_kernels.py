@@ -106,7 +106,9 @@ def test_gemm_persistent_tile_heights_bit_identical(lib, epi, M, N, K):
     """gemm_bf16_s256 (gemm256.hip) with its tile height forced to 256 / 288 / 320 rows (variants 8 / 9 / 10: different
     DMA piece splits and counted waits per height) against the 128-row kernel (variant 1) on the same operands:
     every flavour the forward routes there -- bias, SwiGLU, fp32 head and the bf16-residual read-modify-write --
-    bit for bit, ragged last tiles, one round and several tiles per CU; rows beyond M untouched."""
+    bit for bit, ragged last tiles, one round and several tiles per CU; rows beyond M untouched.  On the taller tiles
+    the bias / SwiGLU / residual flavours run the interleaved LOAD interval (round 3); variant 14 is the library's own
+    choice of height with the sequential interval, variant 0 the default: both are held to the same bits."""
     H = _hip()
     from dark_amd.modeling_dream_length import interleave_gate_up
     g = torch.Generator().manual_seed(epi * 131 + M + N + K)
@@ -121,7 +123,7 @@ def test_gemm_persistent_tile_heights_bit_identical(lib, epi, M, N, K):
     base = torch.randn(M + 2, ldo, generator=g).to(odt).to(DEV)
     outs = {}
     try:
-        for v in (1, 8, 9, 10):
+        for v in (1, 8, 9, 10, 14, 0):
             H.check(lib.dark_dbg_set_gemm_variant(v))
             out = base.clone()
             H.check(lib.dark_dbg_gemm(H.DARK_BF16, epi, H.ptr(A), H.ptr(W), H.ptr(bias) if epi == 0 else None, H.ptr(out),
@@ -131,7 +133,7 @@ def test_gemm_persistent_tile_heights_bit_identical(lib, epi, M, N, K):
     finally:
         H.check(lib.dark_dbg_set_gemm_variant(0))
     assert not torch.equal(outs[1][:M], base[:M])
-    for v in (8, 9, 10):
+    for v in (8, 9, 10, 14, 0):
         assert torch.equal(outs[v][:M].view(torch.int16 if odt == torch.bfloat16 else torch.int32),
                            outs[1][:M].view(torch.int16 if odt == torch.bfloat16 else torch.int32)), (epi, v)
         assert torch.equal(outs[v][M:], base[M:]), "rows beyond M must stay untouched"
